@@ -1,0 +1,239 @@
+"""ctypes/numpy front-end of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: may be imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by the product package (inverse-flow_amd/).
+
+All functions take/return numpy arrays (float32 or float64, C-contiguous NCHW) and follow the
+reference's exact CPU semantics; see invflow_oracle_impl.h for the file:line citations.
+Orders TR/BL/BR are realised by explicit flips of input, weight and output exactly like
+inf/layers/conv.py:192-219 (`reverse_cuda`) -- deliberately different from the in-kernel
+index reflection the HIP path uses, so the two are independent statements.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+ORDERS = ("TL", "TR", "BL", "BR")
+
+
+def build(force=False):
+    """Compile liboracle.so (gcc) and, if the reference checkout exists, oracle/_ref."""
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("invflow_oracle.c", "invflow_oracle_impl.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so", "-B"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/inf"):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = ctypes.CDLL(so)
+        _LIB.orc_logdet_f32.restype = ctypes.c_double
+        _LIB.orc_logdet_f64.restype = ctypes.c_double
+    return _LIB
+
+
+def _suf(a):
+    if a.dtype == np.float32:
+        return "_f32"
+    if a.dtype == np.float64:
+        return "_f64"
+    raise TypeError("oracle handles float32/float64 only, got %s" % a.dtype)
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, dtype=None):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _flip_axes(order):
+    if order not in ORDERS:
+        raise ValueError("unknown order: {}".format(order))
+    ax = []
+    if order[0] == "B":
+        ax.append(2)
+    if order[1] == "R":
+        ax.append(3)
+    return tuple(ax)
+
+
+def _flip(a, order):
+    ax = _flip_axes(order)
+    return _c(np.flip(a, ax)) if ax else a
+
+
+def _run4(name, a, w, diag, order, nthreads):
+    a = _c(a)
+    w = _c(w, a.dtype)
+    B, C, H, W = (int(v) for v in a.shape)
+    KH, KW = (int(v) for v in w.shape[2:])
+    assert w.shape[:2] == (C, C)
+    af, wf = _flip(a, order), _flip(w, order)
+    out = np.empty_like(af)
+    getattr(lib(), name + _suf(a))(_p(af), _p(wf), _p(out), B, C, H, W, KH, KW, int(diag), int(nthreads))
+    return _flip(out, order)
+
+
+def inverse(x, w, diag=0, order="TL", nthreads=1):
+    """z = A^-1 x (solve_mc.py:88-114; diag=1: inverse_op_cython.pyx:17-66)."""
+    return _run4("orc_inverse", x, w, diag, order, nthreads)
+
+
+def forward(z, w, diag=0, order="TL", nthreads=1):
+    """xhat = A z (conv.py:103-108 with the mask of inv_conv.py:233-248)."""
+    return _run4("orc_forward", z, w, diag, order, nthreads)
+
+
+def dy(g, w, diag=0, order="TL", nthreads=1):
+    """dL/dx = A^-T g."""
+    return _run4("orc_dy", g, w, diag, order, nthreads)
+
+
+def dw(z, u, kernel_size, diag=0, order="TL", nthreads=1):
+    """dL/dW = -sum u (x) shifted z, masked (inv_conv.py:223-248)."""
+    z = _c(z)
+    u = _c(u, z.dtype)
+    B, C, H, W = (int(v) for v in z.shape)
+    KH, KW = (int(v) for v in kernel_size)
+    zf, uf = _flip(z, order), _flip(u, order)
+    out = np.empty((C, C, KH, KW), dtype=z.dtype)
+    getattr(lib(), "orc_dw" + _suf(z))(_p(zf), _p(uf), _p(out), B, C, H, W, KH, KW, int(diag), int(nthreads))
+    return _flip(out, order)
+
+
+def logdet(w, H, W, diag=0, order="TL"):
+    """log|det A| per image (emerging_module.py:26-32); 0 for the unit diagonal."""
+    w = _flip(_c(w), order)
+    C = w.shape[0]
+    KH, KW = w.shape[2:]
+    return float(getattr(lib(), "orc_logdet" + _suf(w))(_p(w), int(C), int(H), int(W), int(KH), int(KW), int(diag)))
+
+
+def mask(C, KH, KW, diag=0, order="TL", dtype=np.float32):
+    """Gradient mask of inf/layers/inv_conv.py:233-248 (`get_mask`); diag=1 keeps the diagonal."""
+    m = np.ones((C, C, KH, KW), dtype=dtype)
+    for c in range(C):
+        if not diag:
+            m[c, c, -1, -1] = 0
+        m[c, c + 1:, -1, -1] = 0
+    return _flip(m, order)
+
+
+def effective_weight(w, diag=0, order="TL"):
+    """What: the weight the exact solver actually uses (solve_mc.py:105-109)."""
+    w = _flip(_c(w).copy(), order)
+    C = w.shape[0]
+    for c in range(C):
+        if not diag:
+            w[c, c, -1, -1] = 1
+        w[c, c + 1:, -1, -1] = 0
+    return _flip(w, order)
+
+
+def dense_operator(w, H, W, diag=0, order="TL"):
+    """Dense matrix of A (rows/cols indexed (c,h,w) NCHW-flat) -- independent of the C loops.
+
+    Built by pushing unit impulses through a numpy restatement of
+    F.conv2d(F.pad(., order-pad), What)  (inv_conv.py:126-144 pads, conv.py:103-108).
+    """
+    w = np.asarray(w, dtype=np.float64)
+    C, _, KH, KW = w.shape
+    we = effective_weight(w, diag, order)
+    n = C * H * W
+    A = np.zeros((n, n))
+    top = KH - 1 if order[0] == "T" else 0
+    left = KW - 1 if order[1] == "L" else 0
+    for c in range(C):
+        for h in range(H):
+            for x in range(W):
+                row = (c * H + h) * W + x
+                for kc in range(C):
+                    for kh in range(KH):
+                        ih = h + kh - top
+                        if ih < 0 or ih >= H:
+                            continue
+                        for kw in range(KW):
+                            iw = x + kw - left
+                            if iw < 0 or iw >= W:
+                                continue
+                            A[row, (kc * H + ih) * W + iw] += we[c, kc, kh, kw]
+    return A
+
+
+# ---- self-normalising conv (selfnorm.py) ------------------------------------------------
+
+def conv2d(x, w, bias=None, padding=(0, 0), nthreads=1):
+    x = _c(x)
+    w = _c(w, x.dtype)
+    B, Ci, H, W = x.shape
+    Co, _, KH, KW = w.shape
+    ph, pw = padding
+    OH, OW = H + 2 * ph - KH + 1, W + 2 * pw - KW + 1
+    out = np.empty((B, Co, OH, OW), dtype=x.dtype)
+    b = _c(bias, x.dtype) if bias is not None else None
+    getattr(lib(), "orc_conv2d" + _suf(x))(_p(x), _p(w), _p(b) if b is not None else None, _p(out),
+                                           B, Ci, Co, H, W, KH, KW, ph, pw, int(nthreads))
+    return out
+
+
+def conv2d_wgrad(gz, x, wshape, padding=(0, 0), nthreads=1):
+    x = _c(x)
+    gz = _c(gz, x.dtype)
+    B, Ci, H, W = x.shape
+    Co, _, KH, KW = wshape
+    ph, pw = padding
+    out = np.empty(tuple(wshape), dtype=x.dtype)
+    getattr(lib(), "orc_conv2d_wgrad" + _suf(x))(_p(gz), _p(x), _p(out), B, Ci, Co, H, W, KH, KW, ph, pw,
+                                                 int(nthreads))
+    return out
+
+
+def conv2d_igrad(gz, w, xshape, padding=(0, 0), nthreads=1):
+    gz = _c(gz)
+    w = _c(w, gz.dtype)
+    B, Ci, H, W = xshape
+    Co, _, KH, KW = w.shape
+    ph, pw = padding
+    out = np.empty(tuple(xshape), dtype=gz.dtype)
+    getattr(lib(), "orc_conv2d_igrad" + _suf(gz))(_p(gz), _p(w), _p(out), B, Ci, Co, H, W, KH, KW, ph, pw,
+                                                  int(nthreads))
+    return out
+
+
+def flip_kernel(w):
+    """inf/layers/selfnorm.py:35-36."""
+    return _c(np.flip(w, (2, 3)).transpose(1, 0, 2, 3))
+
+
+def selfnorm_grads(x, W, bw, R, gz, padding):
+    """SelfNormConvFunc.backward, inf/layers/selfnorm.py:52-90 (stride 1, dilation 1, groups 1).
+
+    Returns (input_grad, weight_grad_fwd, bias_grad, weight_grad_inv).
+    """
+    x = _c(x)
+    B = x.shape[0]
+    z = conv2d(x, W, bw, padding)
+    # _compute_weight_multiple, selfnorm.py:24-32
+    multiple = conv2d_wgrad(np.ones_like(z), np.ones_like(x), W.shape, padding) / B
+    delta_z_xt = conv2d_wgrad(gz, x, W.shape, padding)
+    wg_fwd = (delta_z_xt - flip_kernel(R) * multiple) / 2.0
+    input_grad = conv2d_igrad(gz, W, x.shape, padding)
+    Wx = z - bw.reshape(1, -1, 1, 1) if bw is not None else z
+    neg = conv2d_wgrad(-input_grad, Wx, R.shape, padding)
+    wg_inv = (neg + flip_kernel(W) * flip_kernel(multiple)) / 2.0
+    bg = gz.reshape(gz.shape[0], gz.shape[1], -1).sum(-1).sum(0) if bw is not None else None
+    return input_grad, wg_fwd.astype(x.dtype), bg, wg_inv.astype(x.dtype)

@@ -1,0 +1,129 @@
+/*
+ * invflow.h -- C ABI of libinvflow_hip.so: the MI355X (gfx950) implementation of
+ * Inverse-Flow's inverse-of-convolution hot path.
+ *
+ * This is the drop-in boundary.  Each entry point replaces one function of the reference's
+ * pybind11 CUDA extension `inv_conv_with_bp`
+ * (reference: inf/utils/inv_conv_cuda/inv_conv_with_bp_general.cpp:115-120) or one of the
+ * ATen/cuDNN calls of inf/utils/convbackward/conv2d_backward.cpp; the citation above every
+ * prototype names the reference interface it stands in for.  Plain pointers and sizes only:
+ * no torch types, so cgo / JNI / ctypes / pybind can all bind it (INTEGRATION.md shows the
+ * Python stub that the reference's inf/layers/inv_conv.py:21 `import inv_conv_with_bp` resolves to).
+ *
+ * Conventions
+ *   - All tensors are device pointers on the *current HIP device* of the calling thread,
+ *     contiguous NCHW fp32:  x, z, g, dx : (B, C, H, W);  w, dw : (C, C, KH, KW) = [c_out, c_in, kh, kw].
+ *   - `order` is the padding corner of the layer (inf/layers/inv_conv.py:126-144) and `w` is the
+ *     layer's *stored* weight for that order (inf/layers/inv_conv.py:172-179 stores it pre-flipped).
+ *   - The operator is  A = conv2d(pad_order(.), What)  with What = w whose diagonal tap is
+ *     forced to unit-lower-triangular (inf/utils/solve_mc.py:105-109), or -- with
+ *     IFL_FLAG_GENERAL_DIAG -- lower-triangular with w's own diagonal
+ *     (inf/layers/emerging/inverse_op_cython.pyx:64).
+ *   - The library never allocates device memory, never synchronises the device and keeps no
+ *     global mutable state: scratch comes from the caller (`ws`, `ws_bytes`, size from
+ *     ifl_workspace_bytes), work is enqueued on the caller's stream.  Re-entrant and
+ *     thread-safe (the reference: legacy default stream + cudaDeviceSynchronize after every
+ *     launch, inv_conv_with_bp_kernel_general.cu:113-124).
+ *   - Return value: 0 on success, a negative IFL_E* code otherwise; ifl_last_error() gives
+ *     the message for the calling thread.
+ */
+#ifndef INVFLOW_H
+#define INVFLOW_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *ifl_stream_t; /* a hipStream_t (NULL = the null stream) */
+
+enum { IFL_ORDER_TL = 0, IFL_ORDER_TR = 1, IFL_ORDER_BL = 2, IFL_ORDER_BR = 3 };
+
+enum {
+    IFL_FLAG_GENERAL_DIAG = 1u, /* divide by w[c,c,diag tap] instead of assuming 1 */
+    IFL_FLAG_EXACT_F32 = 2u,    /* force the plain-fp32 arithmetic path (no split-precision MFMA) */
+    IFL_FLAG_NO_MFMA = 4u       /* force the general (any C, any K) VALU kernels */
+};
+
+enum { IFL_OK = 0, IFL_EINVAL = -1, IFL_EUNSUPPORTED = -2, IFL_EWORKSPACE = -3, IFL_EHIP = -4 };
+
+enum { IFL_OP_INVERSE = 0, IFL_OP_FORWARD = 1, IFL_OP_BACKWARD = 2, IFL_OP_DY = 3, IFL_OP_DW = 4 };
+
+/* Library / ABI version (major*1000 + minor). */
+int ifl_version(void);
+
+/* Message of the last failing call made by this thread ("" if none). */
+const char *ifl_last_error(void);
+
+/* Scratch bytes the given op needs for this shape (0 is possible).  Negative sizes -> 0. */
+size_t ifl_workspace_bytes(int op, int B, int C, int H, int W, int KH, int KW, unsigned flags);
+
+/*
+ * z = A^-1 x -- the layer's forward pass x -> z.
+ * Replaces  inv_conv_with_bp.inverse(input, kernel, output)
+ *   (inv_conv_with_bp_general.cpp:19-28 -> inv_conv_cuda_inverse, inv_conv_with_bp_kernel_general.cu:72-129),
+ * called from inv_conv_.forward (inf/layers/inv_conv.py:46-60).  Exact semantics = solve_mc.py:88-114.
+ */
+int ifl_inverse_f32(const float *x, const float *w, float *z, int B, int C, int H, int W, int KH, int KW,
+                    int order, unsigned flags, void *ws, size_t ws_bytes, ifl_stream_t stream);
+
+/*
+ * xhat = A z (+ log|det A| per image) -- the layer's reverse / sampling / reconstruction pass.
+ * Replaces  inv_conv_with_bp.forward(input, kernel, output)
+ *   (inv_conv_with_bp_general.cpp:44-53 -> inv_conv_fwd_cuda_inverse, .cu:203-264),
+ * called from inv_flow_*.reverse (inf/layers/inv_conv.py:249-267,442-460).
+ * `logdet` (B floats) may be NULL; it receives H*W*sum_c log|w[c,c,diag tap]|
+ * (inf/layers/emerging/emerging_module.py:26-32) or 0 for the unit diagonal
+ * (inf/layers/inv_conv.py:221).
+ */
+int ifl_forward_f32(const float *z, const float *w, float *xhat, float *logdet, int B, int C, int H, int W,
+                    int KH, int KW, int order, unsigned flags, void *ws, size_t ws_bytes, ifl_stream_t stream);
+
+/*
+ * Fused backward:  dx = A^-T g,  dw = -(sum_b,h,w dx (x) shifted z) * mask   [+ recon term].
+ * Replaces the pair inv_conv_with_bp.dy(...) + inv_conv_with_bp.dw(...)
+ *   (inv_conv_with_bp_general.cpp:70-81,99-112; .cu:408-483,660-735) as called from
+ *   inv_conv_.backward (inf/layers/inv_conv.py:62-81), and the mask of
+ *   inv_flow_with_pad.reset_gradients (inf/layers/inv_conv.py:223-230).
+ * `z` is the saved layer output.  If recon_weight != 0 and `x` != NULL the gradient of
+ *   recon_weight * mean_b ||x - A z||^2   w.r.t. w (z detached; cf. add_recon_grad,
+ *   inf/layers/selfnorm.py:187-229) is accumulated in the same dW reduction and
+ *   `recon_loss` (1 float, may be NULL) receives mean_b ||x - A z||^2.
+ * `dx` may be NULL (weights-only) or `dw` may be NULL (input-gradient only).
+ */
+int ifl_backward_f32(const float *g, const float *z, const float *x, const float *w, float *dx, float *dw,
+                     float recon_weight, float *recon_loss, int B, int C, int H, int W, int KH, int KW,
+                     int order, unsigned flags, void *ws, size_t ws_bytes, ifl_stream_t stream);
+
+/*
+ * Weight gradient from a precomputed dx:  dw = -(sum dx (x) shifted z) * mask.
+ * Second half of inv_conv_with_bp.dw (inv_conv_with_bp_general.cpp:99-112).
+ */
+int ifl_dw_f32(const float *z, const float *dx, float *dw, int B, int C, int H, int W, int KH, int KW,
+               int order, unsigned flags, void *ws, size_t ws_bytes, ifl_stream_t stream);
+
+/* ---- dense convolution pieces of SelfNormConv (inf/layers/selfnorm.py:39-90) ------------------
+ * stride 1, dilation 1, groups 1, symmetric zero padding (ph, pw):
+ *   x : (B, Ci, H, W)   w : (Co, Ci, KH, KW)   z, gz : (B, Co, OH, OW),  OH = H + 2ph - KH + 1.
+ */
+
+/* z = conv2d(x, w) + bias  (bias may be NULL) -- F.conv2d at inf/layers/selfnorm.py:43. */
+int ifl_conv2d_f32(const float *x, const float *w, const float *bias, float *z, int B, int Ci, int Co, int H,
+                   int W, int KH, int KW, int ph, int pw, ifl_stream_t stream);
+
+/* dw = cudnn_convolution_backward_weight(gz, x) -- inf/utils/convbackward/conv2d_backward.cpp:7-28. */
+int ifl_conv2d_wgrad_f32(const float *gz, const float *x, float *dw, int B, int Ci, int Co, int H, int W,
+                         int KH, int KW, int ph, int pw, void *ws, size_t ws_bytes, ifl_stream_t stream);
+
+/* dx = cudnn_convolution_backward_input(gz, w) -- inf/utils/convbackward/conv2d_backward.cpp:32-53. */
+int ifl_conv2d_igrad_f32(const float *gz, const float *w, float *dx, int B, int Ci, int Co, int H, int W,
+                         int KH, int KW, int ph, int pw, void *ws, size_t ws_bytes, ifl_stream_t stream);
+
+/* scratch for the two calls above */
+size_t ifl_conv2d_workspace_bytes(int B, int Ci, int Co, int H, int W, int KH, int KW, int ph, int pw);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INVFLOW_H */

@@ -1,0 +1,272 @@
+// C-ABI entry points of libinvflow_hip.so (see include/invflow.h for the contract and the
+// reference interfaces each one replaces).  Argument validation, workspace carving and
+// kernel selection only -- no device allocation, no synchronisation, no global state.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "ifl_common.h"
+
+namespace ifl {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+void clear_error() { g_err[0] = 0; }
+
+struct Carver {
+    char *base;
+    size_t off, cap;
+    Carver(void *ws, size_t bytes) : base((char *)ws), off(0), cap(bytes) {}
+    template <typename T> T *take(size_t n)
+    {
+        off = align_up(off, 256);
+        T *p = (T *)(base + off);
+        off += n * sizeof(T);
+        return p;
+    }
+    bool ok() const { return off <= cap && (base != nullptr || off == 0); }
+};
+
+static int check_shape(const char *fn, int B, int C, int H, int W, int KH, int KW, int order)
+{
+    if (B < 0 || C < 1 || H < 1 || W < 1 || KH < 1 || KW < 1)
+        IFL_FAIL(IFL_EINVAL, "%s: bad shape B=%d C=%d H=%d W=%d K=%dx%d", fn, B, C, H, W, KH, KW);
+    if (order < IFL_ORDER_TL || order > IFL_ORDER_BR) IFL_FAIL(IFL_EINVAL, "%s: unknown order: %d", fn, order);
+    if ((size_t)B * C * H * W >= ((size_t)1 << 31))
+        IFL_FAIL(IFL_EUNSUPPORTED, "%s: tensor has >= 2^31 elements", fn);
+    return IFL_OK;
+}
+
+static size_t fold_bytes(int C, int KH, int KW)
+{
+    return align_up((size_t)C * C * sizeof(double), 256) + align_up((size_t)KH * KW * C * C * sizeof(float), 256) + 512;
+}
+
+// fold + scan (shared by inverse and dx): z = scan(x) for the operator or its adjoint.
+static int run_scan(const float *x, const float *w, float *z, const Geom &g, int transposed, unsigned flags,
+                    Carver &cv, hipStream_t s)
+{
+    double *linv = cv.take<double>((size_t)g.C * g.C);
+    float *wf = cv.take<float>((size_t)g.KH * g.KW * g.C * g.C);
+    if (!cv.ok()) IFL_FAIL(IFL_EWORKSPACE, "workspace too small: need %zu bytes, have %zu", cv.off, cv.cap);
+    int rc;
+    if ((rc = launch_linv(w, linv, g, s))) return rc;
+    if ((rc = launch_fold(w, linv, wf, g, transposed, s))) return rc;
+    const int rh = g.flipH ^ (transposed ? 1 : 0), rw = g.flipW ^ (transposed ? 1 : 0);
+    (void)flags;
+    return launch_scan_general(x, wf, z, g, rh, rw, s);
+}
+
+// padding corner of the stored-layout convolution for an order (inf/layers/inv_conv.py:126-144)
+static void order_pads(const Geom &g, int &pt, int &pl, int &dkh, int &dkw)
+{
+    pt = g.flipH ? 0 : g.KH - 1;
+    pl = g.flipW ? 0 : g.KW - 1;
+    dkh = g.flipH ? 0 : g.KH - 1; // stored position of the diagonal tap
+    dkw = g.flipW ? 0 : g.KW - 1;
+}
+
+} // namespace ifl
+
+using namespace ifl;
+
+extern "C" {
+
+int ifl_version(void) { return 1000; }
+
+const char *ifl_last_error(void) { return g_err; }
+
+size_t ifl_workspace_bytes(int op, int B, int C, int H, int W, int KH, int KW, unsigned flags)
+{
+    (void)flags;
+    if (B < 0 || C < 1 || H < 1 || W < 1 || KH < 1 || KW < 1) return 0;
+    const size_t n = align_up((size_t)B * C * H * W * sizeof(float), 256) + 256;
+    const size_t wbytes = align_up((size_t)KH * KW * C * C * sizeof(float), 256) + 256;
+    switch (op) {
+    case IFL_OP_INVERSE:
+    case IFL_OP_DY:
+        return fold_bytes(C, KH, KW);
+    case IFL_OP_FORWARD:
+        return wbytes;
+    case IFL_OP_BACKWARD:
+        // fold + (dx when the caller passes none) + (A z and mixed gradient for the recon term)
+        return fold_bytes(C, KH, KW) + wbytes + 3 * n;
+    case IFL_OP_DW:
+        return 0;
+    default:
+        return 0;
+    }
+}
+
+int ifl_inverse_f32(const float *x, const float *w, float *z, int B, int C, int H, int W, int KH, int KW, int order,
+                    unsigned flags, void *ws, size_t ws_bytes, ifl_stream_t stream)
+{
+    clear_error();
+    int rc = check_shape("ifl_inverse_f32", B, C, H, W, KH, KW, order);
+    if (rc) return rc;
+    if (B == 0) return IFL_OK;
+    if (!x || !w || !z) IFL_FAIL(IFL_EINVAL, "ifl_inverse_f32: null tensor pointer");
+    Geom g = make_geom(B, C, H, W, KH, KW, order, flags);
+    Carver cv(ws, ws_bytes);
+    return run_scan(x, w, z, g, 0, flags, cv, (hipStream_t)stream);
+}
+
+int ifl_forward_f32(const float *z, const float *w, float *xhat, float *logdet, int B, int C, int H, int W, int KH,
+                    int KW, int order, unsigned flags, void *ws, size_t ws_bytes, ifl_stream_t stream)
+{
+    clear_error();
+    int rc = check_shape("ifl_forward_f32", B, C, H, W, KH, KW, order);
+    if (rc) return rc;
+    if (B == 0) return IFL_OK;
+    if (!z || !w || !xhat) IFL_FAIL(IFL_EINVAL, "ifl_forward_f32: null tensor pointer");
+    hipStream_t s = (hipStream_t)stream;
+    Geom g = make_geom(B, C, H, W, KH, KW, order, flags);
+    Carver cv(ws, ws_bytes);
+    float *weff = cv.take<float>((size_t)KH * KW * C * C);
+    if (!cv.ok()) IFL_FAIL(IFL_EWORKSPACE, "ifl_forward_f32: workspace too small: need %zu bytes, have %zu", cv.off, cv.cap);
+    if ((rc = launch_effw(w, weff, g, s))) return rc;
+    int pt, pl, dkh, dkw;
+    order_pads(g, pt, pl, dkh, dkw);
+    if ((rc = launch_conv_direct(z, weff, nullptr, xhat, B, C, C, H, W, H, W, KH, KW, pt, pl, s))) return rc;
+    if (logdet && (rc = launch_logdet(w, logdet, g, s))) return rc;
+    return IFL_OK;
+}
+
+int ifl_dw_f32(const float *z, const float *dx, float *dw, int B, int C, int H, int W, int KH, int KW, int order,
+               unsigned flags, void *ws, size_t ws_bytes, ifl_stream_t stream)
+{
+    clear_error();
+    (void)ws;
+    (void)ws_bytes;
+    int rc = check_shape("ifl_dw_f32", B, C, H, W, KH, KW, order);
+    if (rc) return rc;
+    if (!dw || (B > 0 && (!z || !dx))) IFL_FAIL(IFL_EINVAL, "ifl_dw_f32: null tensor pointer");
+    hipStream_t s = (hipStream_t)stream;
+    Geom g = make_geom(B, C, H, W, KH, KW, order, flags);
+    if (B == 0) {
+        IFL_HIP(hipMemsetAsync(dw, 0, (size_t)C * C * KH * KW * sizeof(float), s));
+        return IFL_OK;
+    }
+    int pt, pl, dkh, dkw;
+    order_pads(g, pt, pl, dkh, dkw);
+    return launch_wgrad_direct(dx, z, dw, B, C, C, H, W, H, W, KH, KW, pt, pl, -1.0f, g.general_diag ? 2 : 1, dkh, dkw,
+                               s);
+}
+
+int ifl_backward_f32(const float *gout, const float *z, const float *x, const float *w, float *dx, float *dw,
+                     float recon_weight, float *recon_loss, int B, int C, int H, int W, int KH, int KW, int order,
+                     unsigned flags, void *ws, size_t ws_bytes, ifl_stream_t stream)
+{
+    clear_error();
+    int rc = check_shape("ifl_backward_f32", B, C, H, W, KH, KW, order);
+    if (rc) return rc;
+    if (B > 0 && (!gout || !w)) IFL_FAIL(IFL_EINVAL, "ifl_backward_f32: null tensor pointer");
+    if (B > 0 && dw && !z) IFL_FAIL(IFL_EINVAL, "ifl_backward_f32: dw requested but z is null");
+    if (!dx && !dw) return IFL_OK;
+    hipStream_t s = (hipStream_t)stream;
+    Geom g = make_geom(B, C, H, W, KH, KW, order, flags);
+    const size_t n = (size_t)B * C * H * W;
+    if (B == 0) {
+        if (dw) IFL_HIP(hipMemsetAsync(dw, 0, (size_t)C * C * KH * KW * sizeof(float), s));
+        if (recon_loss) IFL_HIP(hipMemsetAsync(recon_loss, 0, sizeof(float), s));
+        return IFL_OK;
+    }
+    const bool recon = dw && x && recon_weight != 0.0f;
+    Carver cv(ws, ws_bytes);
+    float *u = dx ? dx : cv.take<float>(n);
+    if ((rc = run_scan(gout, w, u, g, 1, flags, cv, s))) return rc;
+    if (!dw) return IFL_OK;
+    const float *gsrc = u;
+    if (recon) {
+        float *weff = cv.take<float>((size_t)KH * KW * C * C);
+        float *az = cv.take<float>(n);
+        float *mix = cv.take<float>(n);
+        if (!cv.ok())
+            IFL_FAIL(IFL_EWORKSPACE, "ifl_backward_f32: workspace too small: need %zu bytes, have %zu", cv.off, cv.cap);
+        int pt, pl, dkh, dkw;
+        order_pads(g, pt, pl, dkh, dkw);
+        if ((rc = launch_effw(w, weff, g, s))) return rc;
+        if ((rc = launch_conv_direct(z, weff, nullptr, az, B, C, C, H, W, H, W, KH, KW, pt, pl, s))) return rc;
+        // d/dW of rw*mean_b||x - A z||^2 = -(2 rw / B) sum r (x) shifted z  -> fold into the dW reduction
+        if ((rc = launch_recon_mix(u, x, az, mix, 2.0f * recon_weight / (float)B, recon_loss, 1.0f / (float)B, n, s)))
+            return rc;
+        gsrc = mix;
+    } else if (recon_loss) {
+        IFL_HIP(hipMemsetAsync(recon_loss, 0, sizeof(float), s));
+    }
+    return ifl_dw_f32(z, gsrc, dw, B, C, H, W, KH, KW, order, flags, nullptr, 0, stream);
+}
+
+// ---- SelfNormConv pieces -------------------------------------------------------------------
+
+static int check_conv(const char *fn, int B, int Ci, int Co, int H, int W, int KH, int KW, int ph, int pw)
+{
+    if (B < 0 || Ci < 1 || Co < 1 || H < 1 || W < 1 || KH < 1 || KW < 1 || ph < 0 || pw < 0)
+        IFL_FAIL(IFL_EINVAL, "%s: bad shape", fn);
+    if (H + 2 * ph - KH + 1 < 1 || W + 2 * pw - KW + 1 < 1) IFL_FAIL(IFL_EINVAL, "%s: kernel larger than padded input", fn);
+    return IFL_OK;
+}
+
+size_t ifl_conv2d_workspace_bytes(int B, int Ci, int Co, int H, int W, int KH, int KW, int ph, int pw)
+{
+    (void)B; (void)H; (void)W; (void)ph; (void)pw;
+    if (Ci < 1 || Co < 1 || KH < 1 || KW < 1) return 0;
+    return align_up((size_t)Ci * Co * KH * KW * sizeof(float), 256) + 256;
+}
+
+int ifl_conv2d_f32(const float *x, const float *w, const float *bias, float *z, int B, int Ci, int Co, int H, int W,
+                   int KH, int KW, int ph, int pw, ifl_stream_t stream)
+{
+    clear_error();
+    int rc = check_conv("ifl_conv2d_f32", B, Ci, Co, H, W, KH, KW, ph, pw);
+    if (rc) return rc;
+    if (!x || !w || !z) IFL_FAIL(IFL_EINVAL, "ifl_conv2d_f32: null tensor pointer");
+    const int OH = H + 2 * ph - KH + 1, OW = W + 2 * pw - KW + 1;
+    return launch_conv_direct(x, w, bias, z, B, Ci, Co, H, W, OH, OW, KH, KW, ph, pw, (hipStream_t)stream);
+}
+
+int ifl_conv2d_wgrad_f32(const float *gz, const float *x, float *dw, int B, int Ci, int Co, int H, int W, int KH,
+                         int KW, int ph, int pw, void *ws, size_t ws_bytes, ifl_stream_t stream)
+{
+    clear_error();
+    (void)ws;
+    (void)ws_bytes;
+    int rc = check_conv("ifl_conv2d_wgrad_f32", B, Ci, Co, H, W, KH, KW, ph, pw);
+    if (rc) return rc;
+    if (!gz || !x || !dw) IFL_FAIL(IFL_EINVAL, "ifl_conv2d_wgrad_f32: null tensor pointer");
+    const int OH = H + 2 * ph - KH + 1, OW = W + 2 * pw - KW + 1;
+    if (B == 0) {
+        IFL_HIP(hipMemsetAsync(dw, 0, (size_t)Ci * Co * KH * KW * sizeof(float), (hipStream_t)stream));
+        return IFL_OK;
+    }
+    return launch_wgrad_direct(gz, x, dw, B, Ci, Co, H, W, OH, OW, KH, KW, ph, pw, 1.0f, 0, 0, 0, (hipStream_t)stream);
+}
+
+int ifl_conv2d_igrad_f32(const float *gz, const float *w, float *dx, int B, int Ci, int Co, int H, int W, int KH,
+                         int KW, int ph, int pw, void *ws, size_t ws_bytes, ifl_stream_t stream)
+{
+    clear_error();
+    int rc = check_conv("ifl_conv2d_igrad_f32", B, Ci, Co, H, W, KH, KW, ph, pw);
+    if (rc) return rc;
+    if (!gz || !w || !dx) IFL_FAIL(IFL_EINVAL, "ifl_conv2d_igrad_f32: null tensor pointer");
+    if (ph > KH - 1 || pw > KW - 1) IFL_FAIL(IFL_EUNSUPPORTED, "ifl_conv2d_igrad_f32: padding larger than K-1");
+    const int OH = H + 2 * ph - KH + 1, OW = W + 2 * pw - KW + 1;
+    hipStream_t s = (hipStream_t)stream;
+    Carver cv(ws, ws_bytes);
+    float *wt = cv.take<float>((size_t)Ci * Co * KH * KW);
+    if (!cv.ok())
+        IFL_FAIL(IFL_EWORKSPACE, "ifl_conv2d_igrad_f32: workspace too small: need %zu bytes, have %zu", cv.off, cv.cap);
+    if ((rc = launch_flip_kernel(w, wt, Co, Ci, KH, KW, s))) return rc;
+    // dx = conv2d(gz, flip_kernel(w), padding = K-1-p): input (B,Co,OH,OW) -> output (B,Ci,H,W)
+    return launch_conv_direct(gz, wt, nullptr, dx, B, Co, Ci, OH, OW, H, W, KH, KW, KH - 1 - ph, KW - 1 - pw, s);
+}
+
+} // extern "C"

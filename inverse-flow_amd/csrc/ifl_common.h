@@ -1,0 +1,80 @@
+// Shared declarations of libinvflow_hip (gfx950).  Internal header: the public C ABI is
+// include/invflow.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/invflow.h"
+
+namespace ifl {
+
+// thread-local error text behind ifl_last_error()
+void set_error(const char *fmt, ...);
+void clear_error();
+
+#define IFL_FAIL(code, ...)         \
+    do {                            \
+        ::ifl::set_error(__VA_ARGS__); \
+        return (code);              \
+    } while (0)
+
+#define IFL_HIP(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) IFL_FAIL(IFL_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Geometry of one inverse-conv problem in *logical* (TL-canonical) coordinates.
+// A layer of order TR/BL/BR is the TL operator seen through a reflection of the pixel grid and
+// of the kernel taps (inf/layers/conv.py:192-219 realises the same thing with torch.flip
+// copies; here the reflection is folded into the addressing, nothing is copied).
+struct Geom {
+    int B, C, H, W, KH, KW;
+    int flipH, flipW; // reflect rows / columns of pixels and taps between logical and stored
+    int general_diag; // IFL_FLAG_GENERAL_DIAG
+};
+
+static inline Geom make_geom(int B, int C, int H, int W, int KH, int KW, int order, unsigned flags)
+{
+    Geom g;
+    g.B = B; g.C = C; g.H = H; g.W = W; g.KH = KH; g.KW = KW;
+    g.flipH = (order == IFL_ORDER_BL || order == IFL_ORDER_BR);
+    g.flipW = (order == IFL_ORDER_TR || order == IFL_ORDER_BR);
+    g.general_diag = (flags & IFL_FLAG_GENERAL_DIAG) ? 1 : 0;
+    return g;
+}
+
+// ---- prep kernels (prep.hip) ---------------------------------------------------------------
+// Linv = L^-1 (double, row-major CxC), L = diagonal-tap matrix of What (unit or general diagonal).
+int launch_linv(const float *w, double *linv, const Geom &g, hipStream_t s);
+// Folded taps Wf[t][kc][c] (float), t = dh*KW+dw:  t=0 -> L^-1 (x tap), t>0 -> L^-1 What_t.
+// transposed!=0 builds the taps of A^T (for dx = A^-T g): L^-T and L^-T What_t^T.
+int launch_fold(const float *w, const double *linv, float *wf, const Geom &g, int transposed, hipStream_t s);
+// What in the stored layout (diagonal tap masked / unit) for the forward conv.
+int launch_effw(const float *w, float *weff, const Geom &g, hipStream_t s);
+// out[b] = H*W*sum_c log|w[c,c,diag tap]|  (0 for the unit diagonal)
+int launch_logdet(const float *w, float *out, const Geom &g, hipStream_t s);
+// wt[ci][co][kh][kw] = w[co][ci][KH-1-kh][KW-1-kw]   (flip_kernel, inf/layers/selfnorm.py:35-36)
+int launch_flip_kernel(const float *w, float *wt, int Co, int Ci, int KH, int KW, hipStream_t s);
+// t = dx + coef*(x - az);  *loss += scale * sum (x-az)^2   (recon term of ifl_backward_f32)
+int launch_recon_mix(const float *dx, const float *x, const float *az, float *t, float coef, float *loss,
+                     float loss_scale, size_t n, hipStream_t s);
+
+// ---- general (any C, any K) VALU kernels (scan_general.hip, conv_general.hip) ----------------
+size_t scan_general_lds_bytes(const Geom &g);
+// z = scan(x) with folded taps wf; pixel reflection (rh, rw) applied to both x and z addressing.
+int launch_scan_general(const float *x, const float *wf, float *z, const Geom &g, int rh, int rw, hipStream_t s);
+
+// out[b][co][oh][ow] = bias[co] + sum w[co][ci][kh][kw] * in[b][ci][oh-pt+kh][ow-pl+kw]
+int launch_conv_direct(const float *in, const float *w, const float *bias, float *out, int B, int Ci, int Co,
+                       int H, int W, int OH, int OW, int KH, int KW, int pt, int pl, hipStream_t s);
+// dw[co][ci][kh][kw] = scale * sum_{b,oh,ow} gz[b][co][oh][ow] * x[b][ci][oh-pt+kh][ow-pl+kw]
+// mask_mode 0: none; 1: zero [co][ci>=co] of tap (mkh,mkw); 2: zero [co][ci>co] of that tap.
+int launch_wgrad_direct(const float *gz, const float *x, float *dw, int B, int Ci, int Co, int H, int W, int OH,
+                        int OW, int KH, int KW, int pt, int pl, float scale, int mask_mode, int mkh, int mkw,
+                        hipStream_t s);
+
+} // namespace ifl

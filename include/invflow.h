@@ -56,6 +56,17 @@ int ifl_version(void);
 /* Message of the last failing call made by this thread ("" if none). */
 const char *ifl_last_error(void);
 
+/*
+ * Optional per-kernel device timing for the calling thread (used by bench.py's roofline leg; the
+ * reference's only timing is a cuda.Event pair around a whole train batch,
+ * inf/train/experiment.py:276-279).  While enabled, each launch of a tagged kernel is bracketed by
+ * hipEvents on the caller's stream; ifl_profile_collect() waits for them, returns the summed
+ * device milliseconds and the launch count for `tag`, and forgets them.
+ */
+enum { IFL_PROF_SCAN = 0, IFL_PROF_WGRAD = 1, IFL_PROF_CONV = 2, IFL_PROF_FOLD = 3 };
+void ifl_profile_enable(int on);
+int ifl_profile_collect(int tag, double *total_ms, int *launches);
+
 /* Scratch bytes the given op needs for this shape (0 is possible).  Negative sizes -> 0. */
 size_t ifl_workspace_bytes(int op, int B, int C, int H, int W, int KH, int KW, unsigned flags);
 

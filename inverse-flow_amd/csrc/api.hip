@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <vector>
+
 #include "ifl_common.h"
 
 namespace ifl {
@@ -20,6 +22,43 @@ void set_error(const char *fmt, ...)
 }
 
 void clear_error() { g_err[0] = 0; }
+
+// ---- optional per-kernel timing (bench.py's roofline leg) -------------------------------------
+// When enabled for the calling thread, every launch of a tagged kernel is bracketed by a pair of
+// hipEvents recorded on the stream the kernel is launched on; ifl_profile_collect() synchronises
+// on them and returns the summed device time per tag.  Disabled (the default) it costs nothing.
+struct ProfRec {
+    hipEvent_t a, b;
+    int tag;
+};
+static thread_local bool g_prof_on = false;
+static thread_local std::vector<ProfRec> g_prof_live;
+static thread_local std::vector<ProfRec> g_prof_pool;
+
+struct ProfScope {
+    hipStream_t s;
+    ProfRec r;
+    bool on;
+    ProfScope(int tag, hipStream_t stream) : s(stream), on(g_prof_on)
+    {
+        if (!on) return;
+        if (!g_prof_pool.empty()) {
+            r = g_prof_pool.back();
+            g_prof_pool.pop_back();
+        } else if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
+            on = false;
+            return;
+        }
+        r.tag = tag;
+        (void)hipEventRecord(r.a, s);
+    }
+    ~ProfScope()
+    {
+        if (!on) return;
+        (void)hipEventRecord(r.b, s);
+        g_prof_live.push_back(r);
+    }
+};
 
 struct Carver {
     char *base;
@@ -58,10 +97,14 @@ static int run_scan(const float *x, const float *w, float *z, const Geom &g, int
     float *wf = cv.take<float>((size_t)g.KH * g.KW * g.C * g.C);
     if (!cv.ok()) IFL_FAIL(IFL_EWORKSPACE, "workspace too small: need %zu bytes, have %zu", cv.off, cv.cap);
     int rc;
-    if ((rc = launch_linv(w, linv, g, s))) return rc;
-    if ((rc = launch_fold(w, linv, wf, g, transposed, s))) return rc;
+    {
+        ProfScope ps(IFL_PROF_FOLD, s);
+        if ((rc = launch_linv(w, linv, g, s))) return rc;
+        if ((rc = launch_fold(w, linv, wf, g, transposed, s))) return rc;
+    }
     const int rh = g.flipH ^ (transposed ? 1 : 0), rw = g.flipW ^ (transposed ? 1 : 0);
     (void)flags;
+    ProfScope ps(IFL_PROF_SCAN, s);
     return launch_scan_general(x, wf, z, g, rh, rw, s);
 }
 
@@ -81,6 +124,34 @@ using namespace ifl;
 extern "C" {
 
 int ifl_version(void) { return 1000; }
+
+void ifl_profile_enable(int on)
+{
+    g_prof_on = on != 0;
+}
+
+int ifl_profile_collect(int tag, double *total_ms, int *launches)
+{
+    double tot = 0.0;
+    int n = 0;
+    std::vector<ProfRec> keep;
+    for (ProfRec &r : g_prof_live) {
+        if (r.tag != tag) {
+            keep.push_back(r);
+            continue;
+        }
+        float ms = 0.f;
+        IFL_HIP(hipEventSynchronize(r.b));
+        IFL_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        tot += ms;
+        ++n;
+        g_prof_pool.push_back(r);
+    }
+    g_prof_live.swap(keep);
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = n;
+    return IFL_OK;
+}
 
 const char *ifl_last_error(void) { return g_err; }
 
@@ -135,7 +206,10 @@ int ifl_forward_f32(const float *z, const float *w, float *xhat, float *logdet, 
     if ((rc = launch_effw(w, weff, g, s))) return rc;
     int pt, pl, dkh, dkw;
     order_pads(g, pt, pl, dkh, dkw);
-    if ((rc = launch_conv_direct(z, weff, nullptr, xhat, B, C, C, H, W, H, W, KH, KW, pt, pl, s))) return rc;
+    {
+        ProfScope ps(IFL_PROF_CONV, s);
+        if ((rc = launch_conv_direct(z, weff, nullptr, xhat, B, C, C, H, W, H, W, KH, KW, pt, pl, s))) return rc;
+    }
     if (logdet && (rc = launch_logdet(w, logdet, g, s))) return rc;
     return IFL_OK;
 }
@@ -157,6 +231,7 @@ int ifl_dw_f32(const float *z, const float *dx, float *dw, int B, int C, int H, 
     }
     int pt, pl, dkh, dkw;
     order_pads(g, pt, pl, dkh, dkw);
+    ProfScope ps(IFL_PROF_WGRAD, s);
     return launch_wgrad_direct(dx, z, dw, B, C, C, H, W, H, W, KH, KW, pt, pl, -1.0f, g.general_diag ? 2 : 1, dkh, dkw,
                                s);
 }

@@ -27,6 +27,8 @@ _vp, _i, _u, _sz, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_si
 SIGNATURES = {
     "ifl_version": (_i, []),
     "ifl_last_error": (ctypes.c_char_p, []),
+    "ifl_profile_enable": (None, [_i]),
+    "ifl_profile_collect": (_i, [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i)]),
     "ifl_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _u]),
     "ifl_inverse_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "ifl_forward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
@@ -54,6 +56,24 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+PROF_TAGS = {"scan": 0, "wgrad": 1, "conv": 2, "fold": 3}
+
+
+def profile_enable(on=True):
+    """Bracket every tagged kernel launch of this thread with hipEvents (bench.py roofline leg)."""
+    lib().ifl_profile_enable(1 if on else 0)
+
+
+def profile_collect():
+    """-> {tag: (total device ms, launches)}; waits for the recorded events."""
+    out = {}
+    for name, tag in PROF_TAGS.items():
+        ms, n = ctypes.c_double(0.0), ctypes.c_int(0)
+        _check(lib().ifl_profile_collect(tag, ctypes.byref(ms), ctypes.byref(n)), "ifl_profile_collect")
+        out[name] = (ms.value, n.value)
+    return out
 
 
 def _check(rc, what):

@@ -94,17 +94,22 @@ static int run_scan(const float *x, const float *w, float *z, const Geom &g, int
                     Carver &cv, hipStream_t s)
 {
     double *linv = cv.take<double>((size_t)g.C * g.C);
-    float *wf = cv.take<float>((size_t)g.KH * g.KW * g.C * g.C);
+    float *wf = cv.take<float>((size_t)g.KH * g.KW * g.C * g.C); // folded taps (fp32) or packed fp16 hi/lo fragments
     if (!cv.ok()) IFL_FAIL(IFL_EWORKSPACE, "workspace too small: need %zu bytes, have %zu", cv.off, cv.cap);
     int rc;
+    const int rh = g.flipH ^ (transposed ? 1 : 0), rw = g.flipW ^ (transposed ? 1 : 0);
+    const bool mfma = !(flags & (IFL_FLAG_NO_MFMA | IFL_FLAG_EXACT_F32)) && scan_mfma_supported(g, x, z);
     {
         ProfScope ps(IFL_PROF_FOLD, s);
         if ((rc = launch_linv(w, linv, g, s))) return rc;
-        if ((rc = launch_fold(w, linv, wf, g, transposed, s))) return rc;
+        if (mfma)
+            rc = launch_pack_mfma(w, linv, wf, g, transposed, s);
+        else
+            rc = launch_fold(w, linv, wf, g, transposed, s);
+        if (rc) return rc;
     }
-    const int rh = g.flipH ^ (transposed ? 1 : 0), rw = g.flipW ^ (transposed ? 1 : 0);
-    (void)flags;
     ProfScope ps(IFL_PROF_SCAN, s);
+    if (mfma) return launch_scan_mfma(x, wf, z, g, rh, rw, s);
     return launch_scan_general(x, wf, z, g, rh, rw, s);
 }
 

@@ -63,6 +63,12 @@ int launch_flip_kernel(const float *w, float *wt, int Co, int Ci, int KH, int KW
 int launch_recon_mix(const float *dx, const float *x, const float *az, float *t, float coef, float *loss,
                      float loss_scale, size_t n, hipStream_t s);
 
+// ---- MFMA scan (scan_mfma.hip): C in {32,64}, K in {2x2,3x3}, H <= 32, W % 4 == 0 -----------------
+bool scan_mfma_supported(const Geom &g, const void *x, const void *z);
+size_t scan_mfma_pack_bytes(const Geom &g);
+int launch_pack_mfma(const float *w, const double *linv, void *apack, const Geom &g, int transposed, hipStream_t s);
+int launch_scan_mfma(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, hipStream_t s);
+
 // ---- general (any C, any K) VALU kernels (scan_general.hip, conv_general.hip) ----------------
 size_t scan_general_lds_bytes(const Geom &g);
 // z = scan(x) with folded taps wf; pixel reflection (rh, rw) applied to both x and z addressing.

@@ -47,20 +47,23 @@ __global__ void k_linv(const float *__restrict__ w, double *__restrict__ linv, G
     }
 }
 
-// Same recurrence with the column kept in LDS (C <= 128): one block, thread j owns column j and
-// only ever reads back its own column, so no barrier is needed.
-__global__ void k_linv_lds(const float *__restrict__ w, double *__restrict__ linv, Geom g)
+// Same recurrence with L and the columns of L^-1 kept in LDS (C <= 96): one block; all threads
+// stage L, then thread j owns column j and only ever reads back its own column.
+__global__ __launch_bounds__(256) void k_linv_lds(const float *__restrict__ w, double *__restrict__ linv, Geom g)
 {
-    extern __shared__ double sl[]; // [i][j]
-    const int j = threadIdx.x;
+    extern __shared__ double sl[]; // [C*C] L^-1 as [i][j], then [C*C] floats of L
     const int C = g.C;
+    float *sL = (float *)(sl + (size_t)C * C);
+    for (int idx = threadIdx.x; idx < C * C; idx += blockDim.x) sL[idx] = (float)l_entry(w, idx / C, idx % C, g);
+    __syncthreads();
+    const int j = threadIdx.x;
     if (j >= C) return;
     for (int i = 0; i < C; ++i) {
         double v = 0.0;
         if (i >= j) {
             double s = (i == j) ? 1.0 : 0.0;
-            for (int k = j; k < i; ++k) s -= l_entry(w, i, k, g) * sl[k * C + j];
-            v = s / l_entry(w, i, i, g);
+            for (int k = j; k < i; ++k) s -= (double)sL[i * C + k] * sl[k * C + j];
+            v = s / (double)sL[i * C + i];
         }
         sl[i * C + j] = v;
         linv[(size_t)i * C + j] = v;
@@ -69,15 +72,14 @@ __global__ void k_linv_lds(const float *__restrict__ w, double *__restrict__ lin
 
 int launch_linv(const float *w, double *linv, const Geom &g, hipStream_t s)
 {
-    if (g.C <= 128) {
-        const size_t lds = (size_t)g.C * g.C * sizeof(double);
+    if (g.C <= 96) {
+        const size_t lds = (size_t)g.C * g.C * (sizeof(double) + sizeof(float));
         static bool attr_done = false; // idempotent attribute, benign race
         if (!attr_done) {
-            IFL_HIP(hipFuncSetAttribute((const void *)k_linv_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 128 * 8));
+            IFL_HIP(hipFuncSetAttribute((const void *)k_linv_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 96 * 12));
             attr_done = true;
         }
-        const int T = (g.C + 63) / 64 * 64;
-        hipLaunchKernelGGL(k_linv_lds, dim3(1), dim3(T), lds, s, w, linv, g);
+        hipLaunchKernelGGL(k_linv_lds, dim3(1), dim3(256), lds, s, w, linv, g);
     } else {
         const int T = 64;
         hipLaunchKernelGGL(k_linv, dim3((g.C + T - 1) / T), dim3(T), 0, s, w, linv, g);

@@ -173,10 +173,10 @@ size_t ifl_workspace_bytes(int op, int B, int C, int H, int W, int KH, int KW, u
     case IFL_OP_FORWARD:
         return wbytes;
     case IFL_OP_BACKWARD:
-        // fold + (dx when the caller passes none) + (A z and mixed gradient for the recon term)
-        return fold_bytes(C, KH, KW) + wbytes + 3 * n;
+        // fold + (dx when the caller passes none) + (A z and mixed gradient for the recon term) + dW partials
+        return fold_bytes(C, KH, KW) + wbytes + 3 * n + wgrad_mfma_workspace_bytes(B, C, H, KH, KW) + 512;
     case IFL_OP_DW:
-        return 0;
+        return wgrad_mfma_workspace_bytes(B, C, H, KH, KW) + 512;
     default:
         return 0;
     }
@@ -223,8 +223,6 @@ int ifl_dw_f32(const float *z, const float *dx, float *dw, int B, int C, int H, 
                unsigned flags, void *ws, size_t ws_bytes, ifl_stream_t stream)
 {
     clear_error();
-    (void)ws;
-    (void)ws_bytes;
     int rc = check_shape("ifl_dw_f32", B, C, H, W, KH, KW, order);
     if (rc) return rc;
     if (!dw || (B > 0 && (!z || !dx))) IFL_FAIL(IFL_EINVAL, "ifl_dw_f32: null tensor pointer");
@@ -237,6 +235,14 @@ int ifl_dw_f32(const float *z, const float *dx, float *dw, int B, int C, int H, 
     int pt, pl, dkh, dkw;
     order_pads(g, pt, pl, dkh, dkw);
     ProfScope ps(IFL_PROF_WGRAD, s);
+    if (!(flags & (IFL_FLAG_NO_MFMA | IFL_FLAG_EXACT_F32)) && wgrad_mfma_supported(B, C, H, W, KH, KW, pt, pl, dx, z)) {
+        Carver cv(ws, ws_bytes);
+        void *wws = cv.take<char>(wgrad_mfma_workspace_bytes(B, C, H, KH, KW));
+        if (cv.ok())
+            return launch_wgrad_mfma(dx, z, dw, wws, B, C, H, W, KH, KW, pt, pl, -1.0f, g.general_diag ? 2 : 1, dkh,
+                                     dkw, s);
+        IFL_FAIL(IFL_EWORKSPACE, "ifl_dw_f32: workspace too small: need %zu bytes, have %zu", cv.off, cv.cap);
+    }
     return launch_wgrad_direct(dx, z, dw, B, C, C, H, W, H, W, KH, KW, pt, pl, -1.0f, g.general_diag ? 2 : 1, dkh, dkw,
                                s);
 }
@@ -282,7 +288,13 @@ int ifl_backward_f32(const float *gout, const float *z, const float *x, const fl
     } else if (recon_loss) {
         IFL_HIP(hipMemsetAsync(recon_loss, 0, sizeof(float), s));
     }
-    return ifl_dw_f32(z, gsrc, dw, B, C, H, W, KH, KW, order, flags, nullptr, 0, stream);
+    {
+        // hand the rest of the workspace to the dW reduction
+        cv.off = align_up(cv.off, 256);
+        char *rest = cv.base ? cv.base + cv.off : nullptr;
+        const size_t rest_bytes = cv.cap > cv.off ? cv.cap - cv.off : 0;
+        return ifl_dw_f32(z, gsrc, dw, B, C, H, W, KH, KW, order, flags, rest, rest_bytes, stream);
+    }
 }
 
 // ---- SelfNormConv pieces -------------------------------------------------------------------

@@ -69,6 +69,12 @@ size_t scan_mfma_pack_bytes(const Geom &g);
 int launch_pack_mfma(const float *w, const double *linv, void *apack, const Geom &g, int transposed, hipStream_t s);
 int launch_scan_mfma(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, hipStream_t s);
 
+// ---- MFMA weight gradient (wgrad_mfma.hip): C in {32,64}, W in {16,32}, K in {2x2,3x3}, corner pads ----
+bool wgrad_mfma_supported(int B, int C, int H, int W, int KH, int KW, int pt, int pl, const void *gz, const void *x);
+size_t wgrad_mfma_workspace_bytes(int B, int C, int H, int KH, int KW);
+int launch_wgrad_mfma(const float *gz, const float *x, float *dw, void *ws, int B, int C, int H, int W, int KH, int KW,
+                      int pt, int pl, float scale, int mask_mode, int mkh, int mkw, hipStream_t s);
+
 // ---- general (any C, any K) VALU kernels (scan_general.hip, conv_general.hip) ----------------
 size_t scan_general_lds_bytes(const Geom &g);
 // z = scan(x) with folded taps wf; pixel reflection (rh, rw) applied to both x and z addressing.

@@ -1,0 +1,407 @@
+// MFMA weight gradient of the inverse conv (gfx950, wave64):
+//     dW[co][ci][kh][kw] = scale * sum_{b,oh,ow} gz[b][co][oh][ow] * x[b][ci][oh-pt+kh][ow-pl+kw]
+// for the four padding corners (pt in {0,KH-1}, pl in {0,KW-1}; inf/layers/inv_conv.py:126-144),
+// i.e. the dense contraction M=C, N=C*KH*KW, K=B*H*W of SURVEY 2.2 (reference: 2*80 serial
+// launches + a 302 MB scratch tensor, inv_conv_with_bp_kernel_general.cu:496-735).
+//
+// Everything is expressed in *stored* coordinates through one canonical form
+//     G[p][q][i][j] = sum_{b,r,s} a[b][p][r][s+j] * bb[b][q][r - sg*i][s]        (zero outside the image)
+// with (a, bb, sg) = (gz, x, +1) TL, (gz, x, -1) BL, (x, gz, -1) TR, (x, gz, +1) BR; for the R orders
+// G is the transpose of dW (handled by the reduce kernel).  The reduction index of an MFMA is the
+// column s of one image row: both operands are then 8 consecutive floats per lane straight from
+// NCHW memory -- no im2col, no LDS transposes.  Row r - sg*i of bb is simply the fragment converted
+// i row-steps earlier (rolling registers), the column shift s+j of a is made in registers from the
+// unshifted fragment (v_alignbit + one cross-half shuffle for the carried-in head).
+//
+// Work split: output block = 32x32 channels (one v_mfma_f32_32x32x16_f16 tile per tap), one wave owns
+// one block for a run of RPW consecutive rows of one image (its slice of the K dimension); the four
+// waves of a workgroup own four K-slices of the same block and tree-reduce through LDS, so one fp32
+// partial per workgroup goes to memory (9.4 MB at the north-star shape) and a second kernel sums the
+// partials in a fixed order (deterministic; no float atomics), applies sign/scale, the gradient mask
+// (inf/layers/inv_conv.py:223-248) and the tap index map.
+//
+// Arithmetic: split fp16 (hi = fp16(v), lo = fp16(v - hi), denormals kept -- verified on gfx950 by
+// tools/mfma_f16_denorm_probe.hip) after a power-of-two per-tensor prescale that puts max|v| at 2^6,
+// three MFMAs per k-step (hi*hi + hi*lo + lo*hi), fp32 accumulation.
+#include "ifl_common.h"
+
+namespace ifl {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+static constexpr int WG_RPW = 16; // image rows per wave (K-slice)
+
+// ---- max|v| of two tensors (bit pattern of a non-negative float orders like an unsigned) ---------
+__global__ __launch_bounds__(256) void k_absmax2(const float *__restrict__ a, const float *__restrict__ b, size_t n,
+                                                 unsigned *__restrict__ out)
+{
+    float ma = 0.f, mb = 0.f;
+    const size_t n4 = n / 4;
+    const floatx4 *a4 = (const floatx4 *)a, *b4 = (const floatx4 *)b;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const floatx4 va = a4[i], vb = b4[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ma = fmaxf(ma, fabsf(va[j]));
+            mb = fmaxf(mb, fabsf(vb[j]));
+        }
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
+            ma = fmaxf(ma, fabsf(a[i]));
+            mb = fmaxf(mb, fabsf(b[i]));
+        }
+    for (int o = 32; o > 0; o >>= 1) {
+        ma = fmaxf(ma, __shfl_down(ma, o, 64));
+        mb = fmaxf(mb, __shfl_down(mb, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        // NaN/Inf propagate as a huge pattern -> scale 2^-k, results stay NaN/Inf: loud, not silent
+        atomicMax(out + 0, __float_as_uint(ma));
+        atomicMax(out + 1, __float_as_uint(mb));
+    }
+}
+
+// power of two s with s*max in [2^6, 2^7)  (1 if max is 0 or not finite)
+__device__ __forceinline__ float pow2_scale(unsigned maxbits)
+{
+    const int e = (int)((maxbits >> 23) & 0xff);
+    if (maxbits == 0u || e == 0xff) return 1.0f;
+    int se = 127 + 6 - (e - 127); // exponent field of the scale
+    se = se < 1 ? 1 : (se > 254 ? 254 : se);
+    return __uint_as_float((unsigned)se << 23);
+}
+
+__device__ __forceinline__ void split8(const floatx4 &v0, const floatx4 &v1, float s, half8 &hi, half8 &lo)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float x0 = v0[j] * s, x1 = v1[j] * s;
+        const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+        hi[j] = h0;
+        hi[4 + j] = h1;
+        lo[j] = (_Float16)(x0 - (float)h0);
+        lo[4 + j] = (_Float16)(x1 - (float)h1);
+    }
+}
+
+// fragment shifted forward by J columns: element k <- element k+J; `head` = first dword of the next
+// 8-column block (already exchanged across the wave halves)
+template <int J> __device__ __forceinline__ half8 shift_frag(const half8 &f, unsigned head)
+{
+    const uintx4 d = __builtin_bit_cast(uintx4, f);
+    uintx4 o;
+    if (J == 0) {
+        o = d;
+    } else if (J == 1) {
+        o[0] = __builtin_amdgcn_alignbit(d[1], d[0], 16);
+        o[1] = __builtin_amdgcn_alignbit(d[2], d[1], 16);
+        o[2] = __builtin_amdgcn_alignbit(d[3], d[2], 16);
+        o[3] = __builtin_amdgcn_alignbit(head, d[3], 16);
+    } else {
+        o[0] = d[1];
+        o[1] = d[2];
+        o[2] = d[3];
+        o[3] = head;
+    }
+    return __builtin_bit_cast(half8, o);
+}
+
+// C channels, KHxKW taps (KW <= 3), NKS = W/16 k-steps per image row
+template <int C, int KH, int KW, int NKS>
+__global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a, const float *__restrict__ bb,
+                                                    float *__restrict__ partial, const unsigned *__restrict__ absmax,
+                                                    int a_is_first, int B, int H, int sg, int ntask)
+{
+    constexpr int W = 16 * NKS;
+    constexpr int NT = KH * KW;
+    constexpr int NB = C / 32; // 32-channel blocks per side
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int m = lane & 31, hh = lane >> 5;
+    const int blk = blockIdx.x % (NB * NB), split = blockIdx.x / (NB * NB);
+    const int bp = blk / NB, bq = blk % NB; // block row (a channels) / column (bb channels)
+
+    // absmax[0] belongs to the tensor passed first to the launcher (gz), [1] to the second (x)
+    const float sa = pow2_scale(absmax[a_is_first ? 0 : 1]);
+    const float sb = pow2_scale(absmax[a_is_first ? 1 : 0]);
+
+    floatx16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int rgroups = (H + WG_RPW - 1) / WG_RPW;
+    const int task = split * 4 + wv; // (image, row group)
+    if (task < ntask) {
+        const int b = task / rgroups, rg = task % rgroups;
+        const int r_lo = rg * WG_RPW, r_hi = (r_lo + WG_RPW < H ? r_lo + WG_RPW : H) - 1;
+        // walk rows in direction sg so that rows r - sg*i were seen i steps earlier
+        const int r_first = sg > 0 ? r_lo : r_hi;
+        const int nrows = r_hi - r_lo + 1;
+        const float *ap = a + ((size_t)b * C + 32 * bp + m) * H * W + 8 * hh;
+        const float *bpz = bb + ((size_t)b * C + 32 * bq + m) * H * W + 8 * hh;
+
+        half8 Bz[KH][NKS][2]; // rolling rows of bb: [0] current, [i] i steps earlier
+#pragma unroll
+        for (int i = 0; i < KH; ++i)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) Bz[i][ks][hl][j] = (_Float16)0.f;
+
+        // halo: the KH-1 rows of bb before the first row of this slice
+#pragma unroll
+        for (int i = KH - 1; i >= 1; --i) {
+            const int r = r_first - sg * i;
+            if (r >= 0 && r < H) {
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const floatx4 v0 = *(const floatx4 *)(bpz + (size_t)r * W + 16 * ks);
+                    const floatx4 v1 = *(const floatx4 *)(bpz + (size_t)r * W + 16 * ks + 4);
+                    split8(v0, v1, sb, Bz[i][ks][0], Bz[i][ks][1]);
+                }
+            }
+        }
+
+        // raw prefetch registers for the current row
+        floatx4 ra[NKS][2], rb[NKS][2];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            ra[ks][0] = *(const floatx4 *)(ap + (size_t)r_first * W + 16 * ks);
+            ra[ks][1] = *(const floatx4 *)(ap + (size_t)r_first * W + 16 * ks + 4);
+            rb[ks][0] = *(const floatx4 *)(bpz + (size_t)r_first * W + 16 * ks);
+            rb[ks][1] = *(const floatx4 *)(bpz + (size_t)r_first * W + 16 * ks + 4);
+        }
+
+        for (int step = 0; step < nrows; ++step) {
+            const int r = r_first + sg * step;
+            // convert the row that was prefetched, then prefetch the next one
+            half8 Au[NKS][2];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                split8(ra[ks][0], ra[ks][1], sa, Au[ks][0], Au[ks][1]);
+                split8(rb[ks][0], rb[ks][1], sb, Bz[0][ks][0], Bz[0][ks][1]);
+            }
+            if (step + 1 < nrows) {
+                const int rn = r + sg;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    ra[ks][0] = *(const floatx4 *)(ap + (size_t)rn * W + 16 * ks);
+                    ra[ks][1] = *(const floatx4 *)(ap + (size_t)rn * W + 16 * ks + 4);
+                    rb[ks][0] = *(const floatx4 *)(bpz + (size_t)rn * W + 16 * ks);
+                    rb[ks][1] = *(const floatx4 *)(bpz + (size_t)rn * W + 16 * ks + 4);
+                }
+            }
+            // heads of the next 8-column block, exchanged across the two wave halves:
+            // a lane with hh=0 needs the hh=1 lane's block of the same k-step, a lane with hh=1 the
+            // hh=0 lane's block of the next k-step (zero past the row end)
+            unsigned head[NKS][2];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) {
+                    const unsigned own = __builtin_bit_cast(uintx4, Au[ks][hl])[0];
+                    const unsigned nxt = ks + 1 < NKS ? __builtin_bit_cast(uintx4, Au[ks + 1 < NKS ? ks + 1 : ks][hl])[0] : 0u;
+                    const unsigned send = hh ? own : nxt;
+                    head[ks][hl] = (unsigned)__shfl_xor((int)send, 32, 64);
+                }
+            // note: the hh=1 lane of the LAST k-step receives `nxt` of its partner = 0 (row end) as
+            // intended; the hh=0 lane receives the partner's own block.
+
+#define IFL_WG_TAPS(J)                                                                                             \
+    {                                                                                                              \
+        half8 As[NKS][2];                                                                                          \
+        _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks) _Pragma("unroll") for (int hl = 0; hl < 2; ++hl)        \
+            As[ks][hl] = shift_frag<J>(Au[ks][hl], head[ks][hl]);                                                  \
+        _Pragma("unroll") for (int i = 0; i < KH; ++i) _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks)          \
+        {                                                                                                          \
+            floatx16 c_ = acc[i * KW + J];                                                                         \
+            c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(As[ks][0], Bz[i][ks][0], c_, 0, 0, 0);                     \
+            c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(As[ks][0], Bz[i][ks][1], c_, 0, 0, 0);                     \
+            c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(As[ks][1], Bz[i][ks][0], c_, 0, 0, 0);                     \
+            acc[i * KW + J] = c_;                                                                                  \
+        }                                                                                                          \
+    }
+            IFL_WG_TAPS(0)
+            if constexpr (KW > 1) IFL_WG_TAPS(1)
+            if constexpr (KW > 2) IFL_WG_TAPS(2)
+#undef IFL_WG_TAPS
+
+            // roll the rows of bb
+#pragma unroll
+            for (int i = KH - 1; i >= 1; --i)
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                    for (int hl = 0; hl < 2; ++hl) Bz[i][ks][hl] = Bz[i - 1][ks][hl];
+            (void)r;
+        }
+    }
+
+    // ---- tree reduction of the four waves' accumulators through LDS (fixed order) ----------------
+    floatx4 *red = (floatx4 *)smem; // [2][NT*4][64] float4
+    constexpr int NV = NT * 4;      // float4 vectors per lane
+    if (wv >= 2) {
+        floatx4 *dst = red + (size_t)(wv - 2) * NV * 64;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                dst[(t * 4 + v) * 64 + lane] = floatx4{acc[t][4 * v], acc[t][4 * v + 1], acc[t][4 * v + 2], acc[t][4 * v + 3]};
+    }
+    __syncthreads();
+    if (wv < 2) {
+        const floatx4 *src = red + (size_t)wv * NV * 64;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const floatx4 o = src[(t * 4 + v) * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t][4 * v + e] += o[e];
+            }
+    }
+    __syncthreads();
+    if (wv == 1) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                red[(t * 4 + v) * 64 + lane] = floatx4{acc[t][4 * v], acc[t][4 * v + 1], acc[t][4 * v + 2], acc[t][4 * v + 3]};
+    }
+    __syncthreads();
+    if (wv == 0) {
+        // partial[split][t][p][q] with p = 32bp + row, q = 32bq + col (unscaled: the reduce kernel divides)
+        float *out = partial + (size_t)split * NT * C * C;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const floatx4 o = red[(t * 4 + v) * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int reg = 4 * v + e;
+                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh; // C/D layout of 32x32 MFMA
+                    out[((size_t)t * C + 32 * bp + row) * C + 32 * bq + m] = acc[t][reg] + o[e];
+                }
+            }
+    }
+}
+
+// dw[co][ci][kh][kw] = scale/(sa*sb) * sum_splits partial[s][t=(i,j)][p][q], p/q = (co,ci) or (ci,co)
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ partial, float *__restrict__ dw,
+                                                      const unsigned *__restrict__ absmax, int nsplit, int C, int KH,
+                                                      int KW, int swapped, int top, int left, float scale,
+                                                      int mask_mode, int mkh, int mkw)
+{
+    const int NT = KH * KW;
+    const size_t total = (size_t)NT * C * C;
+    const float inv = scale / (pow2_scale(absmax[0]) * pow2_scale(absmax[1]));
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % C), p = (int)((idx / C) % C), t = (int)(idx / ((size_t)C * C));
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * total + idx];
+        const int i = t / KW, j = t % KW;
+        const int kh = top ? KH - 1 - i : i, kw = left ? KW - 1 - j : j;
+        const int co = swapped ? q : p, ci = swapped ? p : q;
+        float v = s * inv;
+        if (mask_mode && kh == mkh && kw == mkw) {
+            if (mask_mode == 1 && ci >= co) v = 0.f;
+            if (mask_mode == 2 && ci > co) v = 0.f;
+        }
+        dw[(((size_t)co * C + ci) * KH + kh) * KW + kw] = v;
+    }
+}
+
+bool wgrad_mfma_supported(int B, int C, int H, int W, int KH, int KW, int pt, int pl, const void *gz, const void *x)
+{
+    if (!(C == 32 || C == 64)) return false;
+    if (!(W == 16 || W == 32)) return false;
+    if (KH < 1 || KH > 3 || KW < 1 || KW > 3 || KH != KW) return false;
+    if (!(KH == 3 || KH == 2)) return false;
+    if (!((pt == 0 || pt == KH - 1) && (pl == 0 || pl == KW - 1))) return false;
+    if (KH == 1 || KW == 1) return false;
+    if (B < 1 || H < 1) return false;
+    if (((uintptr_t)gz | (uintptr_t)x) & 15) return false;
+    return true;
+}
+
+static int wgrad_ntask(int B, int H) { return B * ((H + WG_RPW - 1) / WG_RPW); }
+
+size_t wgrad_mfma_workspace_bytes(int B, int C, int H, int KH, int KW)
+{
+    const int nsplit = (wgrad_ntask(B, H) + 3) / 4;
+    return 256 + (size_t)nsplit * KH * KW * C * C * sizeof(float);
+}
+
+template <int C, int KH, int KW, int NKS>
+static int launch_wg(const float *a, const float *bb, float *partial, const unsigned *absmax, int a_is_first, int B,
+                     int H, int sg, hipStream_t s)
+{
+    const int ntask = wgrad_ntask(B, H);
+    const int nsplit = (ntask + 3) / 4;
+    constexpr int NB = C / 32;
+    const size_t lds = (size_t)2 * KH * KW * 4 * 64 * sizeof(floatx4);
+    static bool attr_done = false; // idempotent attribute, benign race
+    if (!attr_done) {
+        IFL_HIP(hipFuncSetAttribute((const void *)k_wgrad_mfma<C, KH, KW, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_wgrad_mfma<C, KH, KW, NKS>), dim3(nsplit * NB * NB), dim3(256), lds, s, a, bb, partial, absmax,
+                       a_is_first, B, H, sg, ntask);
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+
+int launch_wgrad_mfma(const float *gz, const float *x, float *dw, void *ws, int B, int C, int H, int W, int KH, int KW,
+                      int pt, int pl, float scale, int mask_mode, int mkh, int mkw, hipStream_t s)
+{
+    unsigned *absmax = (unsigned *)ws;
+    float *partial = (float *)((char *)ws + 256);
+    const size_t n = (size_t)B * C * H * W;
+    IFL_HIP(hipMemsetAsync(absmax, 0, 2 * sizeof(unsigned), s));
+    {
+        size_t blocks = (n / 4 + 255) / 256;
+        if (blocks > 1024) blocks = 1024;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(k_absmax2, dim3((unsigned)blocks), dim3(256), 0, s, gz, x, n, absmax);
+        IFL_HIP(hipGetLastError());
+    }
+    const int top = pt != 0, left = pl != 0;
+    // canonical form (see header): L orders shift gz, R orders shift x and transpose the result
+    const int swapped = !left;
+    const float *a = swapped ? x : gz, *bb = swapped ? gz : x;
+    const int sg = (top != swapped) ? +1 : -1; // TL:+1  BL:-1  TR:-1  BR:+1
+    int rc = IFL_EUNSUPPORTED;
+#define IFL_CASE(CC, KK, NN) \
+    if (C == CC && KH == KK && W == 16 * NN) rc = launch_wg<CC, KK, KK, NN>(a, bb, partial, absmax, swapped ? 0 : 1, B, H, sg, s);
+    IFL_CASE(64, 3, 2)
+    IFL_CASE(64, 3, 1)
+    IFL_CASE(32, 3, 2)
+    IFL_CASE(32, 3, 1)
+    IFL_CASE(64, 2, 2)
+    IFL_CASE(64, 2, 1)
+    IFL_CASE(32, 2, 2)
+    IFL_CASE(32, 2, 1)
+#undef IFL_CASE
+    if (rc == IFL_EUNSUPPORTED) IFL_FAIL(rc, "launch_wgrad_mfma: no instantiation for C=%d K=%d W=%d", C, KH, W);
+    if (rc) return rc;
+    const int nsplit = (wgrad_ntask(B, H) + 3) / 4;
+    const size_t total = (size_t)KH * KW * C * C;
+    size_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)blocks), dim3(256), 0, s, partial, dw, absmax, nsplit, C, KH, KW,
+                       swapped, top, left, scale, mask_mode, mkh, mkw);
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+
+} // namespace ifl

@@ -203,8 +203,10 @@ def backward(g, z, w, order="TL", flags=0, x=None, recon_weight=0.0, need_dx=Tru
     L = lib()
     with torch.cuda.device(dev):
         nb = L.ifl_workspace_bytes(OP_BACKWARD, B, C, H, W, KH, KW, flags)
-        if need_dx and not recon:  # no temporaries beyond the fold needed
+        if need_dx and not recon:  # no activation-sized temporaries needed: fold (+ dW partials)
             nb = L.ifl_workspace_bytes(OP_DY, B, C, H, W, KH, KW, flags)
+            if need_dw:
+                nb += L.ifl_workspace_bytes(OP_DW, B, C, H, W, KH, KW, flags) + 512
         ws = _ws(nb, dev)
         rc = L.ifl_backward_f32(_ptr(g), _ptr(z) if need_dw else None, _ptr(x) if recon else None, _ptr(w), _ptr(dx),
                                 _ptr(dw), float(recon_weight) if recon else 0.0, _ptr(rl), B, C, H, W, KH, KW,
@@ -225,7 +227,9 @@ def dw_from(z, dx, kernel_size, order="TL", flags=0, out=None):
     dev = _same_device(z, dx, out)
     L = lib()
     with torch.cuda.device(dev):
-        rc = L.ifl_dw_f32(_ptr(z), _ptr(dx), _ptr(out), B, C, H, W, KH, KW, _order(order), flags, None, 0,
+        nb = L.ifl_workspace_bytes(OP_DW, B, C, H, W, KH, KW, flags)
+        ws = _ws(nb, dev)
+        rc = L.ifl_dw_f32(_ptr(z), _ptr(dx), _ptr(out), B, C, H, W, KH, KW, _order(order), flags, _ptr(ws), nb,
                           torch.cuda.current_stream().cuda_stream)
     _check(rc, "ifl_dw_f32")
     return out

@@ -101,11 +101,12 @@ static int run_scan(const float *x, const float *w, float *z, const Geom &g, int
     const bool mfma = !(flags & (IFL_FLAG_NO_MFMA | IFL_FLAG_EXACT_F32)) && scan_mfma_supported(g, x, z);
     {
         ProfScope ps(IFL_PROF_FOLD, s);
-        if ((rc = launch_linv(w, linv, g, s))) return rc;
-        if (mfma)
-            rc = launch_pack_mfma(w, linv, wf, g, transposed, s);
-        else
+        if (mfma) {
+            rc = launch_foldpack_mfma(w, wf, g, transposed, s);
+        } else {
+            if ((rc = launch_linv(w, linv, g, s))) return rc;
             rc = launch_fold(w, linv, wf, g, transposed, s);
+        }
         if (rc) return rc;
     }
     ProfScope ps(IFL_PROF_SCAN, s);

@@ -66,7 +66,7 @@ int launch_recon_mix(const float *dx, const float *x, const float *az, float *t,
 // ---- MFMA scan (scan_mfma.hip): C in {32,64}, K in {2x2,3x3}, H <= 32, W % 4 == 0 -----------------
 bool scan_mfma_supported(const Geom &g, const void *x, const void *z);
 size_t scan_mfma_pack_bytes(const Geom &g);
-int launch_pack_mfma(const float *w, const double *linv, void *apack, const Geom &g, int transposed, hipStream_t s);
+int launch_foldpack_mfma(const float *w, void *apack, const Geom &g, int transposed, hipStream_t s);
 int launch_scan_mfma(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, hipStream_t s);
 
 // ---- MFMA weight gradient (wgrad_mfma.hip): C in {32,64}, W in {16,32}, K in {2x2,3x3}, corner pads ----

@@ -22,6 +22,8 @@
 // ah = fp16(a), al' = fp16((a-ah) 2^11): three v_mfma_f32_16x16x32_f16 per 32-deep k-step, the
 // dropped al*bl term is 2^-22 relative.  The folded weights live in registers for the whole scan
 // (144 VGPRs at C=64, K=3).
+#include <type_traits>
+
 #include "ifl_common.h"
 
 namespace ifl {
@@ -51,7 +53,7 @@ __device__ __forceinline__ void ins4(floatx4 &v, int i, float x)
 }
 
 template <int C, int KH, int KW, int NTILE> struct ScanCfg {
-    static constexpr int NW = C / 16;          // waves = 16-channel output groups
+    static constexpr int NW = C / 16;          // compute waves = 16-channel output groups
     static constexpr int NQ = C / 32;          // 32-deep k-steps per tap
     static constexpr int NT = KH * KW;         // taps incl. the diagonal one
     static constexpr int NS = NT;              // A slots: NT-1 folded taps + 1 post matrix (L^-1)
@@ -60,25 +62,92 @@ template <int C, int KH, int KW, int NTILE> struct ScanCfg {
     static constexpr int ROWB = 4 * C + 16;    // bytes per ring row: hi C*2 | lo C*2 | 16 pad
     static constexpr int NROW = 16 * NTILE + PADR;
     static constexpr int SLOTB = NROW * ROWB;
-    static constexpr int LDSB = R * SLOTB;
+    static constexpr int RINGB = R * SLOTB;
+    // x staging: [row h][quad parity][channel] 16-byte quads, filled by the loader wave's LDS-DMA
+    static constexpr int XSB = 16 * NTILE * 2 * C * 16;
+    static constexpr int LDSB = RINGB + XSB;
     static constexpr int THREADS = 64 * NW;
+    static constexpr int ROWS_PER_ITER = 4 * NTILE;      // rows that need their next quad each step
+    static constexpr int G = ROWS_PER_ITER / NW;         // LDS-DMA instructions per wave and step
+    static_assert(ROWS_PER_ITER % NW == 0, "rows per step must split evenly over the waves");
 };
 
+// x staging.  Every step each wave issues G global_load_lds_dwordx4 (LDS-DMA: no VGPR destination,
+// nothing for the compiler to track): for a row h that is one step into a quad (w = d-h = 1 mod 4) it
+// brings the *next* quad x[:, h, w+3 .. w+6] of all C channels (lane = channel) into the slot
+// [h][quad parity].  The quad is first read 3 steps later.  Its slot-mate (two quads back) was read for
+// the last time in phase C of step d-2, which every wave left before the barrier of step d-1, so the
+// DMA cannot overwrite data that is still being read.
 template <int C, int KH, int KW, int NTILE>
-__global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__restrict__ xin, float *__restrict__ zout,
-                                                             const half8 *__restrict__ apack, int H, int W, int rh,
-                                                             int rw)
+__device__ __forceinline__ void scan_issue_dma(const float *__restrict__ xin, unsigned char *xs, int b, int wv, int lane,
+                                               int d, int H, int W, int rh, int rw)
+{
+    using Cfg = ScanCfg<C, KH, KW, NTILE>;
+    static_assert(C <= 64, "one LDS-DMA instruction covers one image row of all channels");
+    const int c = lane < C ? lane : 0;
+    const int ph = (((d - 1) % 4) + 4) % 4;
+#pragma unroll
+    for (int i = 0; i < Cfg::G; ++i) {
+        const int h = ph + 4 * (wv * Cfg::G + i);
+        const int wq = d - h + 3; // first column of the next quad of that row
+        const int qslot = (wq >> 2) & 1;
+        // out-of-range rows / quads: load something valid into the slot, nobody reads it -- the
+        // instruction is issued unconditionally so that the number of VM operations per step is exact
+        const bool ok = h < H && wq >= 0 && wq < W;
+        const int hc = ok ? h : 0, wc = ok ? wq : 0;
+        const int hs = rh ? H - 1 - hc : hc;
+        const int ws = rw ? W - 4 - wc : wc;
+        const float *src = xin + (((size_t)b * C + c) * H + hs) * W + ws;
+        unsigned char *dst = xs + (size_t)((h * 2 + qslot) * C) * 16; // wave-uniform; lane c lands at +16c
+        if (C == 64 || lane < C)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)src,
+                                             (void __attribute__((address_space(3))) *)dst, 16, 0, 0);
+    }
+}
+
+// "all but the n youngest vector-memory operations of this wave are complete", LDS drained, then the
+// workgroup barrier.  n is exact (see the step body), so the wave never waits for anything younger than
+// the DMA it needs -- in particular not for its own recent z stores, which share the same counter.
+__device__ __forceinline__ void wait_vm_then_barrier(int n)
+{
+#define IFL_W(N) \
+    case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    switch (n) {
+        IFL_W(0) IFL_W(1) IFL_W(2) IFL_W(3) IFL_W(4) IFL_W(5) IFL_W(6) IFL_W(7) IFL_W(8) IFL_W(9) IFL_W(10) IFL_W(11)
+        IFL_W(12) IFL_W(13) IFL_W(14) IFL_W(15) IFL_W(16) IFL_W(17) IFL_W(18) IFL_W(19) IFL_W(20) IFL_W(21) IFL_W(22)
+        IFL_W(23) IFL_W(24) IFL_W(25) IFL_W(26) IFL_W(27) IFL_W(28) IFL_W(29) IFL_W(30) IFL_W(31) IFL_W(32) IFL_W(33)
+        IFL_W(34) IFL_W(35) IFL_W(36) IFL_W(37) IFL_W(38) IFL_W(39) IFL_W(40) IFL_W(41) IFL_W(42) IFL_W(43) IFL_W(44)
+        IFL_W(45) IFL_W(46) IFL_W(47) IFL_W(48)
+    default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    }
+#undef IFL_W
+}
+
+template <int C, int KH, int KW, int NTILE>
+__global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__restrict__ xin,
+                                                                 float *__restrict__ zout,
+                                                                 const half8 *__restrict__ apack, int H, int W, int rh,
+                                                                 int rw)
 {
     using Cfg = ScanCfg<C, KH, KW, NTILE>;
     constexpr int NQ = Cfg::NQ, NT = Cfg::NT, NS = Cfg::NS, R = Cfg::R, PADR = Cfg::PADR, ROWB = Cfg::ROWB,
                   SLOTB = Cfg::SLOTB;
-    __shared__ __attribute__((aligned(16))) unsigned char ring[Cfg::LDSB];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char *ring = lds;
+    unsigned char *xs = lds + Cfg::RINGB;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
     const int b = blockIdx.x;
     const int ND = H + W - 1;
+
+    // ---- zero the ring (zero padding of the operator) ------------------------------------------------
+    {
+        const floatx4 zz = {0.f, 0.f, 0.f, 0.f};
+        for (int i = tid * 16; i < Cfg::RINGB; i += Cfg::THREADS * 16) *(floatx4 *)(ring + i) = zz;
+    }
+    __syncthreads();
 
     // ---- folded weights -> registers (A fragments, hi and lo) -----------------------------------
     half8 A[NS][NQ][2];
@@ -87,13 +156,12 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int hl = 0; hl < 2; ++hl) A[s][q][hl] = apack[((((size_t)wv * NS + s) * NQ + q) * 2 + hl) * 64 + lane];
-
-    // ---- zero the ring (zero padding of the operator) ------------------------------------------------
-    {
-        const floatx4 zz = {0.f, 0.f, 0.f, 0.f};
-        for (int i = tid * 16; i < Cfg::LDSB; i += Cfg::THREADS * 16) *(floatx4 *)(ring + i) = zz;
-    }
+            for (int hl = 0; hl < 2; ++hl) {
+                A[s][q][hl] = apack[((((size_t)wv * NS + s) * NQ + q) * 2 + hl) * 64 + lane];
+                // pin the fragment in the accumulator half of the register file (MFMA reads A from AGPRs
+                // directly); without this hipcc re-loads the weights from memory inside the scan loop
+                asm volatile("" : "+a"(A[s][q][hl]));
+            }
 
     // ---- per-lane constants -------------------------------------------------------------------
     const int c0 = 16 * wv + 4 * g; // first of this lane's 4 output channels (C/D layout rows)
@@ -102,7 +170,8 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
     size_t gbase[NTILE];            // element offset of (b, c0, stored row, 0)
     int rbase[NTILE];               // LDS byte offset of (row h, k-group g) inside a slot
     int wbase[NTILE];               // LDS byte offset of this lane's 4 hi halves inside a slot
-    floatx4 xc[NTILE][4], xn[NTILE][4], zo[NTILE][4];
+    int xbase[NTILE];               // LDS byte offset of this lane's first x quad (row h, parity 0, channel c0)
+    floatx4 zo[NTILE][4];
 #pragma unroll
     for (int T = 0; T < NTILE; ++T) {
         hrow[T] = 16 * T + n;
@@ -111,12 +180,9 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
         gbase[T] = (((size_t)b * C + c0) * H + (hval[T] ? hs : 0)) * W;
         rbase[T] = (hrow[T] + PADR) * ROWB + g * 16;
         wbase[T] = (hrow[T] + PADR) * ROWB + c0 * 2;
+        xbase[T] = ((hrow[T] * 2) * C + c0) * 16;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            xc[T][r] = floatx4{0.f, 0.f, 0.f, 0.f};
-            xn[T][r] = floatx4{0.f, 0.f, 0.f, 0.f};
-            zo[T][r] = floatx4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int r = 0; r < 4; ++r) zo[T][r] = floatx4{0.f, 0.f, 0.f, 0.f};
     }
     const size_t cstride = (size_t)H * W;
 
@@ -125,87 +191,142 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
 #pragma unroll
     for (int k = 0; k < R; ++k) soff[k] = ((R - k) % R) * SLOTB;
 
-    __syncthreads();
+    int nst[3] = {0, 0, 0}; // store instructions this wave issued in the previous three steps
 
-    for (int d = -4; d <= ND; ++d) {
+    // One step of the scan, specialised on the set of active tiles (bit T of MASK) so that its body is
+    // straight-line code: the LDS fragment reads are software-pipelined one (tap, k-step) unit ahead of
+    // the MFMAs that consume them and the tiles are interleaved, which keeps the matrix pipe fed from a
+    // single wave per SIMD.
+    auto step = [&](auto mask_c, const int d) {
+        constexpr int MASK = decltype(mask_c)::value;
         floatx4 ahi[NTILE], amid[NTILE];
-        bool act[NTILE];
 #pragma unroll
         for (int T = 0; T < NTILE; ++T) {
             ahi[T] = floatx4{0.f, 0.f, 0.f, 0.f};
             amid[T] = floatx4{0.f, 0.f, 0.f, 0.f};
-            // wave-uniform: does tile T hold any pixel of diagonal d?
-            act[T] = d >= 16 * T && d <= 16 * T + 15 + W - 1 && d < ND && 16 * T < H;
         }
+        half8 fh[2][NTILE], fl[2][NTILE];
 
-        // ---- (A) x quads: enter the next quad / prefetch the one after -------------------------
-#pragma unroll
-        for (int T = 0; T < NTILE; ++T) {
-            const int w = d - hrow[T];
-            if (hval[T] && (w & 3) == 0) {
-                if (w >= 0 && w < W) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) xc[T][r] = xn[T][r];
+        // x quads needed three steps from now
+        scan_issue_dma<C, KH, KW, NTILE>(xin, xs, b, wv, lane, d, H, W, rh, rw);
+
+        // unit u of a phase = (tap, k-step); SEL: 0 -> taps two or more diagonals back, 1 -> the two
+        // taps on diagonal d-1
+        auto run_phase = [&](auto sel_c) {
+            constexpr int SEL = decltype(sel_c)::value;
+            constexpr int NU = []() {
+                int c = 0;
+                for (int t = 1; t < NT; ++t) {
+                    const int s2 = t / KW + t % KW;
+                    if (SEL ? s2 == 1 : s2 >= 2) c += NQ;
                 }
-                const int wq = w + 4;
-                if (wq >= 0 && wq < W) {
-                    const int ws = rw ? W - 4 - wq : wq;
+                return c;
+            }();
+            auto unit_tap = [](int u) {
+                int c = 0;
+                for (int t = 1; t < NT; ++t) {
+                    const int s2 = t / KW + t % KW;
+                    if (SEL ? s2 == 1 : s2 >= 2) {
+                        if (u < c + NQ) return t;
+                        c += NQ;
+                    }
+                }
+                return 1;
+            };
+            auto unit_q = [](int u) {
+                int c = 0;
+                for (int t = 1; t < NT; ++t) {
+                    const int s2 = t / KW + t % KW;
+                    if (SEL ? s2 == 1 : s2 >= 2) {
+                        if (u < c + NQ) return u - c;
+                        c += NQ;
+                    }
+                }
+                return 0;
+            };
+            auto load_unit = [&](int u, int buf) {
+                const int t = unit_tap(u), q = unit_q(u), dh = t / KW, dw = t % KW;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        xn[T][r] = *(const floatx4 *)(xin + gbase[T] + r * cstride + ws);
+                for (int T = 0; T < NTILE; ++T)
+                    if (MASK & (1 << T)) {
+                        const unsigned char *rowp = ring + soff[dh + dw] + rbase[T] - dh * ROWB + q * 64;
+                        fh[buf][T] = *(const half8 *)(rowp);
+                        fl[buf][T] = *(const half8 *)(rowp + 2 * C);
+                    }
+            };
+            if constexpr (NU > 0) {
+                load_unit(0, 0);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    if (u + 1 < NU) load_unit(u + 1, (u + 1) & 1);
+                    const int t = unit_tap(u), q = unit_q(u);
+#pragma unroll
+                    for (int T = 0; T < NTILE; ++T)
+                        if (MASK & (1 << T)) {
+                            ahi[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], fh[u & 1][T], ahi[T], 0, 0, 0);
+                            amid[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], fl[u & 1][T], amid[T], 0, 0, 0);
+                            amid[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][1], fh[u & 1][T], amid[T], 0, 0, 0);
+                        }
                 }
             }
-        }
+        };
 
         // ---- (B) taps whose sources are two or more diagonals back: no dependence on step d-1 ----
+        run_phase(std::integral_constant<int, 0>{});
+
+        // The quads this wave DMA'd three steps ago must have landed before anyone reads them in phase C:
+        // younger than those are exactly the stores of steps d-3..d-1 and the DMAs of steps d-2..d.
+        // Then the barrier: r of diagonal d-1 is complete in the ring.
+        wait_vm_then_barrier(3 * Cfg::G + nst[0] + nst[1] + nst[2]);
+
+        // ---- (C) x of this step, the two taps on diagonal d-1 ---------------------------------------
+        float xv[NTILE][4];
+#pragma unroll
+        for (int T = 0; T < NTILE; ++T)
+            if (MASK & (1 << T)) {
+                const int w = d - hrow[T];
+                // this lane's 4 x values: quad (w>>2) of row h, channels c0..c0+3, element w&3
+                const unsigned char *xp = xs + xbase[T] + ((w >> 2) & 1) * (C * 16) + (rw ? 3 - (w & 3) : (w & 3)) * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xv[T][r] = *(const float *)(xp + r * 16);
+            }
+        run_phase(std::integral_constant<int, 1>{});
+
+        // ---- (D) z of diagonal d-1 = L^-1 r: independent MFMAs issued before the epilogue's VALU work so
+        //      that the matrix pipe stays busy while r_d is converted and written ----------------------
+        floatx4 zh[NTILE], zm[NTILE];
+        bool actz[NTILE];
 #pragma unroll
         for (int T = 0; T < NTILE; ++T) {
-            if (act[T]) {
+            actz[T] = d - 1 >= 16 * T && d - 1 <= 16 * T + 15 + W - 1 && d >= 1 && 16 * T < H;
+            zh[T] = floatx4{0.f, 0.f, 0.f, 0.f};
+            zm[T] = floatx4{0.f, 0.f, 0.f, 0.f};
+            if (actz[T]) {
+                const unsigned char *rowp = ring + soff[1] + rbase[T];
+                half8 bh[NQ], bl[NQ];
 #pragma unroll
-                for (int t = 1; t < NT; ++t) {
-                    const int dh = t / KW, dw = t % KW;
-                    if (dh + dw >= 2) {
-                        const unsigned char *rowp = ring + soff[dh + dw] + rbase[T] - dh * ROWB;
+                for (int q = 0; q < NQ; ++q) {
+                    bh[q] = *(const half8 *)(rowp + q * 64);
+                    bl[q] = *(const half8 *)(rowp + 2 * C + q * 64);
+                }
 #pragma unroll
-                        for (int q = 0; q < NQ; ++q) {
-                            const half8 bh = *(const half8 *)(rowp + q * 64);
-                            const half8 bl = *(const half8 *)(rowp + 2 * C + q * 64);
-                            ahi[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], bh, ahi[T], 0, 0, 0);
-                            amid[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], bl, amid[T], 0, 0, 0);
-                            amid[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][1], bh, amid[T], 0, 0, 0);
-                        }
-                    }
+                for (int q = 0; q < NQ; ++q) {
+                    zh[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[NS - 1][q][0], bh[q], zh[T], 0, 0, 0);
+                    zm[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[NS - 1][q][0], bl[q], zm[T], 0, 0, 0);
+                    zm[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[NS - 1][q][1], bh[q], zm[T], 0, 0, 0);
                 }
             }
         }
 
-        __syncthreads(); // r of diagonal d-1 is complete in the ring
-
-        // ---- (C) the two taps on diagonal d-1, then r_d -> ring ---------------------------------------
+        // ---- epilogue: r_d -> split fp16 -> ring ---------------------------------------------------------
 #pragma unroll
-        for (int T = 0; T < NTILE; ++T) {
-            if (act[T]) {
-#pragma unroll
-                for (int t = 1; t < NT; ++t) {
-                    const int dh = t / KW, dw = t % KW;
-                    if (dh + dw == 1) {
-                        const unsigned char *rowp = ring + soff[1] + rbase[T] - dh * ROWB;
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q) {
-                            const half8 bh = *(const half8 *)(rowp + q * 64);
-                            const half8 bl = *(const half8 *)(rowp + 2 * C + q * 64);
-                            ahi[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], bh, ahi[T], 0, 0, 0);
-                            amid[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], bl, amid[T], 0, 0, 0);
-                            amid[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][1], bh, amid[T], 0, 0, 0);
-                        }
-                    }
-                }
+        for (int T = 0; T < NTILE; ++T)
+            if (MASK & (1 << T)) {
                 const int w = d - hrow[T];
-                const int ph = rw ? 3 - (w & 3) : (w & 3);
                 half4 hi, lo;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float rv = sel4(xc[T][r], ph) + ahi[T][r] + amid[T][r] * LO_INV;
+                    const float rv = xv[T][r] + ahi[T][r] + amid[T][r] * LO_INV;
                     const _Float16 h16 = (_Float16)rv;
                     hi[r] = h16;
                     lo[r] = (_Float16)((rv - (float)h16) * LO_SCALE);
@@ -215,34 +336,29 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
                     *(half4 *)(ring + soff[0] + wbase[T] + 2 * C) = lo;
                 }
             }
-        }
 
-        // ---- (D) z of diagonal d-1 = L^-1 r (off the chain), gathered into quads and stored ----
+        // ---- z quads: gather, store when a quad is complete -----------------------------------------
+        int nstore = 0; // exact number of store instructions this wave issues in this step
 #pragma unroll
-        for (int T = 0; T < NTILE; ++T) {
-            const bool actz = d - 1 >= 16 * T && d - 1 <= 16 * T + 15 + W - 1 && d >= 1 && 16 * T < H;
-            if (actz) {
-                floatx4 zh = {0.f, 0.f, 0.f, 0.f}, zm = {0.f, 0.f, 0.f, 0.f};
-                const unsigned char *rowp = ring + soff[1] + rbase[T];
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const half8 bh = *(const half8 *)(rowp + q * 64);
-                    const half8 bl = *(const half8 *)(rowp + 2 * C + q * 64);
-                    zh = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[NS - 1][q][0], bh, zh, 0, 0, 0);
-                    zm = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[NS - 1][q][0], bl, zm, 0, 0, 0);
-                    zm = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[NS - 1][q][1], bh, zm, 0, 0, 0);
-                }
+        for (int T = 0; T < NTILE; ++T)
+            if (actz[T]) {
                 const int wz = d - 1 - hrow[T];
                 const int phz = rw ? 3 - (wz & 3) : (wz & 3);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ins4(zo[T][r], phz, zh[r] + zm[r] * LO_INV);
-                if (hval[T] && wz >= 0 && wz < W && (wz & 3) == 3) {
-                    const int ws = rw ? W - 1 - wz : wz - 3;
+                for (int r = 0; r < 4; ++r) ins4(zo[T][r], phz, zh[T][r] + zm[T][r] * LO_INV);
+                const bool st = hval[T] && wz >= 0 && wz < W && (wz & 3) == 3;
+                if (__builtin_amdgcn_ballot_w64(st) != 0) { // wave-uniform: the stores below are issued
+                    nstore += 4;
+                    if (st) {
+                        const int ws = rw ? W - 1 - wz : wz - 3;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) *(floatx4 *)(zout + gbase[T] + r * cstride + ws) = zo[T][r];
+                        for (int r = 0; r < 4; ++r) *(floatx4 *)(zout + gbase[T] + r * cstride + ws) = zo[T][r];
+                    }
                 }
             }
-        }
+        nst[2] = nst[1];
+        nst[1] = nst[0];
+        nst[0] = nstore;
 
         // rotate the slot table: diagonal d+1 takes the slot of diagonal d-(R-1)
         {
@@ -251,14 +367,37 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
             for (int k = R - 1; k > 0; --k) soff[k] = soff[k - 1];
             soff[0] = last;
         }
+    };
+
+    for (int d = -4; d <= ND; ++d) {
+        int mask = 0;
+#pragma unroll
+        for (int T = 0; T < NTILE; ++T)
+            // wave-uniform: does tile T hold any pixel of diagonal d?
+            if (d >= 16 * T && d <= 16 * T + 15 + W - 1 && d < ND && 16 * T < H) mask |= 1 << T;
+        if (NTILE == 2 && mask == 3)
+            step(std::integral_constant<int, (NTILE == 2 ? 3 : 1)>{}, d);
+        else if (NTILE == 2 && mask == 2)
+            step(std::integral_constant<int, (NTILE == 2 ? 2 : 1)>{}, d);
+        else if (mask == 1)
+            step(std::integral_constant<int, 1>{}, d);
+        else
+            step(std::integral_constant<int, 0>{}, d);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fold + pack for the MFMA scan: A fragments in the exact per-lane register image.
+// Fused fold + pack for the MFMA scan: one launch builds the A fragments in the exact per-lane
+// register image.
 //   slot s < NT-1 : -(W_t L^-1)          (t = s+1; transposed: -(W_t^T L^-T))
 //   slot NT-1     :  L^-1                (transposed: L^-T)
 // apack[wv][s][q][hl][lane][j] (fp16),  lane = m + 16*gk holds row c = 16wv+m, k = 32q + 8gk + j.
+//
+// Grid = NT slots x C/16 row groups.  Every workgroup first inverts L in LDS (fp64) by 16x16
+// blocks -- diagonal blocks by substitution (16 dependent steps), off-diagonal blocks
+// X_ij = -X_ii (sum_k L_ik X_kj) level by level -- which cuts the 64-step serial substitution of
+// the exact solver's channel loop (solve_mc.py:96-109) to ~16 + 2(C/16-1) short dependent stages,
+// then forms its 16 rows of the product and splits them into fp16 hi / lo*2^11.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ size_t w_index2(int co, int ci, int dh, int dw, int C, int KH, int KW, int flipH,
                                            int flipW)
@@ -269,38 +408,124 @@ __device__ __forceinline__ size_t w_index2(int co, int ci, int dh, int dw, int C
     return (((size_t)co * C + ci) * KH + kh) * KW + kw;
 }
 
-__global__ void k_pack_mfma(const float *__restrict__ w, const double *__restrict__ linv, _Float16 *__restrict__ apack,
-                            Geom g, int transposed)
+template <int C>
+__global__ __launch_bounds__(256) void k_foldpack(const float *__restrict__ w, _Float16 *__restrict__ apack, Geom g,
+                                                  int transposed)
 {
-    const int C = g.C, NT = g.KH * g.KW, NQ = C / 32;
-    const size_t total = (size_t)NT * C * C;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int kc = (int)(i % C);
-        const int c = (int)((i / C) % C);
-        const int s = (int)(i / ((size_t)C * C));
+    constexpr int NBK = C / 16, XP = C + 1; // XP: fp64 row pitch (conflict-free row- and column-wise)
+    __shared__ float sL[C * C];
+    __shared__ double sX[C * XP];
+    __shared__ double sS[(NBK > 1 ? NBK - 1 : 1) * 256];
+    __shared__ float sW[16 * C];
+    const int tid = threadIdx.x;
+    const int NT = g.KH * g.KW, RG = C / 16, NQ = C / 32;
+    const int s = blockIdx.x / RG, rgrp = blockIdx.x % RG;
+
+    // ---- L (effective diagonal tap) and this workgroup's 16 rows of W_t ----------------------------
+    for (int idx = tid; idx < C * C; idx += 256) {
+        const int i = idx / C, k = idx % C;
+        float v = 0.f;
+        if (k < i) v = w[w_index2(i, k, 0, 0, C, g.KH, g.KW, g.flipH, g.flipW)];
+        else if (k == i) v = g.general_diag ? w[w_index2(i, i, 0, 0, C, g.KH, g.KW, g.flipH, g.flipW)] : 1.f;
+        sL[idx] = v;
+    }
+    if (s < NT - 1) {
+        const int t = s + 1, dh = t / g.KW, dw = t % g.KW;
+        for (int idx = tid; idx < 16 * C; idx += 256) {
+            const int cl = idx / C, m = idx % C, c = 16 * rgrp + cl;
+            sW[idx] = transposed ? w[w_index2(m, c, dh, dw, C, g.KH, g.KW, g.flipH, g.flipW)]
+                                 : w[w_index2(c, m, dh, dw, C, g.KH, g.KW, g.flipH, g.flipW)];
+        }
+    }
+    for (int idx = tid; idx < C * XP; idx += 256) sX[idx] = 0.0;
+    __syncthreads();
+
+    // ---- diagonal blocks of L^-1: column j by forward substitution inside its 16x16 block; the column
+    //      lives in registers (fully unrolled), L comes from LDS and does not depend on the chain ------
+    if (tid < C) {
+        const int j = tid, r0 = (j / 16) * 16, jj = j % 16;
+        double col[16];
+#pragma unroll
+        for (int ii = 0; ii < 16; ++ii) {
+            double a0 = (ii == jj) ? 1.0 : 0.0, a1 = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < 16; kk += 2) {
+                if (kk < ii) a0 -= (double)sL[(r0 + ii) * C + r0 + kk] * (kk >= jj ? col[kk] : 0.0);
+                if (kk + 1 < ii) a1 -= (double)sL[(r0 + ii) * C + r0 + kk + 1] * (kk + 1 >= jj ? col[kk + 1] : 0.0);
+            }
+            col[ii] = ii >= jj ? (a0 + a1) / (double)sL[(r0 + ii) * C + r0 + ii] : 0.0;
+            sX[(r0 + ii) * XP + j] = col[ii];
+        }
+    }
+    __syncthreads();
+
+    // ---- off-diagonal blocks, one block-distance at a time ----------------------------------------
+    {
+        const int r = tid / 16, cc = tid % 16;
+#pragma unroll 1
+        for (int dist = 1; dist < NBK; ++dist) {
+            const int npairs = NBK - dist;
+            for (int p = 0; p < npairs; ++p) {
+                const int bi = p + dist, bj = p;
+                const int row = 16 * bi + r, col = 16 * bj + cc;
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                for (int kb = bj; kb < bi; ++kb) {
+#pragma unroll
+                    for (int kk = 0; kk < 16; kk += 4) {
+                        const int k = 16 * kb + kk;
+                        a0 += (double)sL[row * C + k] * sX[k * XP + col];
+                        a1 += (double)sL[row * C + k + 1] * sX[(k + 1) * XP + col];
+                        a2 += (double)sL[row * C + k + 2] * sX[(k + 2) * XP + col];
+                        a3 += (double)sL[row * C + k + 3] * sX[(k + 3) * XP + col];
+                    }
+                }
+                sS[p * 256 + tid] = (a0 + a1) + (a2 + a3);
+            }
+            __syncthreads();
+            for (int p = 0; p < npairs; ++p) {
+                const int bi = p + dist, bj = p;
+                const int row = 16 * bi + r, col = 16 * bj + cc;
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int kk = 0; kk < 16; kk += 2) {
+                    // X_ii is lower triangular: entries with kk > r are exactly zero in sX
+                    a0 += sX[row * XP + 16 * bi + kk] * sS[p * 256 + kk * 16 + cc];
+                    a1 += sX[row * XP + 16 * bi + kk + 1] * sS[p * 256 + (kk + 1) * 16 + cc];
+                }
+                sX[row * XP + col] = -(a0 + a1);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- this workgroup's 16 rows of the slot: product, split, pack ------------------------------------
+    for (int idx = tid; idx < 16 * C; idx += 256) {
+        const int cl = idx / C, kc = idx % C, c = 16 * rgrp + cl;
         double acc = 0.0;
         if (s == NT - 1) {
-            acc = transposed ? linv[(size_t)kc * C + c] : linv[(size_t)c * C + kc];
+            acc = transposed ? sX[kc * XP + c] : sX[c * XP + kc];
         } else {
-            const int t = s + 1, dh = t / g.KW, dw = t % g.KW;
-            if (!transposed) {
-                // (W_t L^-1)[c][kc] = sum_{m>=kc} w[c][m][t] Linv[m][kc]
-                for (int m = kc; m < C; ++m)
-                    acc += (double)w[w_index2(c, m, dh, dw, C, g.KH, g.KW, g.flipH, g.flipW)] * linv[(size_t)m * C + kc];
-            } else {
-                // (W_t^T L^-T)[c][kc] = sum_{m<=kc} w[m][c][t] Linv[kc][m]
-                for (int m = 0; m <= kc; ++m)
-                    acc += (double)w[w_index2(m, c, dh, dw, C, g.KH, g.KW, g.flipH, g.flipW)] * linv[(size_t)kc * C + m];
+            // normal:     (W_t L^-1)[c][kc]     = sum_m W_t[c][m] Linv[m][kc]   (Linv[m][kc] = 0 for m < kc)
+            // transposed: (W_t^T L^-T)[c][kc]   = sum_m W_t[m][c] Linv[kc][m]   (Linv[kc][m] = 0 for m > kc)
+            // the zeros are stored, so the sums run over all m: fixed trip count, unrolled, 4 chains
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            const int xs_m = transposed ? 1 : XP, xs_0 = transposed ? kc * XP : kc;
+#pragma unroll 4
+            for (int m = 0; m < C; m += 4) {
+                a0 += (double)sW[cl * C + m] * sX[xs_0 + m * xs_m];
+                a1 += (double)sW[cl * C + m + 1] * sX[xs_0 + (m + 1) * xs_m];
+                a2 += (double)sW[cl * C + m + 2] * sX[xs_0 + (m + 2) * xs_m];
+                a3 += (double)sW[cl * C + m + 3] * sX[xs_0 + (m + 3) * xs_m];
             }
-            acc = -acc;
+            acc = -((a0 + a1) + (a2 + a3));
         }
         const float v = (float)acc;
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)((v - (float)hi) * LO_SCALE);
-        const int wv = c / 16, m16 = c % 16, q = kc / 32, gk = (kc % 32) / 8, j = kc % 8;
-        const size_t base = ((((size_t)wv * NT + s) * NQ + q) * 2) * 64 * 8;
-        apack[base + (size_t)(m16 + 16 * gk) * 8 + j] = hi;
-        apack[base + (size_t)64 * 8 + (size_t)(m16 + 16 * gk) * 8 + j] = lo;
+        const int q = kc / 32, gk = (kc % 32) / 8, j = kc % 8;
+        const size_t base = ((((size_t)rgrp * NT + s) * NQ + q) * 2) * 64 * 8;
+        apack[base + (size_t)(cl + 16 * gk) * 8 + j] = hi;
+        apack[base + (size_t)64 * 8 + (size_t)(cl + 16 * gk) * 8 + j] = lo;
     }
 }
 
@@ -315,12 +540,15 @@ bool scan_mfma_supported(const Geom &g, const void *x, const void *z)
     return true;
 }
 
-int launch_pack_mfma(const float *w, const double *linv, void *apack, const Geom &g, int transposed, hipStream_t s)
+int launch_foldpack_mfma(const float *w, void *apack, const Geom &g, int transposed, hipStream_t s)
 {
-    const size_t total = (size_t)g.KH * g.KW * g.C * g.C;
-    size_t blocks = (total + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_pack_mfma, dim3((unsigned)blocks), dim3(256), 0, s, w, linv, (_Float16 *)apack, g, transposed);
+    const int blocks = g.KH * g.KW * (g.C / 16);
+    if (g.C == 64)
+        hipLaunchKernelGGL(k_foldpack<64>, dim3(blocks), dim3(256), 0, s, w, (_Float16 *)apack, g, transposed);
+    else if (g.C == 32)
+        hipLaunchKernelGGL(k_foldpack<32>, dim3(blocks), dim3(256), 0, s, w, (_Float16 *)apack, g, transposed);
+    else
+        IFL_FAIL(IFL_EUNSUPPORTED, "launch_foldpack_mfma: C=%d", g.C);
     IFL_HIP(hipGetLastError());
     return IFL_OK;
 }
@@ -328,8 +556,16 @@ int launch_pack_mfma(const float *w, const double *linv, void *apack, const Geom
 template <int C, int KH, int KW, int NTILE>
 static int launch_one(const float *x, float *z, const void *apack, const Geom &g, int rh, int rw, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_scan_mfma<C, KH, KW, NTILE>), dim3(g.B), dim3(64 * (C / 16)), 0, s, x, z, (const half8 *)apack,
-                       g.H, g.W, rh, rw);
+    using Cfg = ScanCfg<C, KH, KW, NTILE>;
+    static_assert(Cfg::LDSB <= 160 * 1024, "ring + x staging must fit the CU's LDS");
+    static bool attr_done = false; // idempotent attribute, benign race
+    if (!attr_done) {
+        IFL_HIP(hipFuncSetAttribute((const void *)k_scan_mfma<C, KH, KW, NTILE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    Cfg::LDSB));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_scan_mfma<C, KH, KW, NTILE>), dim3(g.B), dim3(Cfg::THREADS), Cfg::LDSB, s, x, z,
+                       (const half8 *)apack, g.H, g.W, rh, rw);
     IFL_HIP(hipGetLastError());
     return IFL_OK;
 }

@@ -58,8 +58,17 @@ __global__ __launch_bounds__(256) void k_absmax2(const float *__restrict__ a, co
         ma = fmaxf(ma, __shfl_down(ma, o, 64));
         mb = fmaxf(mb, __shfl_down(mb, o, 64));
     }
+    __shared__ float red[2][4];
     if ((threadIdx.x & 63) == 0) {
-        // NaN/Inf propagate as a huge pattern -> scale 2^-k, results stay NaN/Inf: loud, not silent
+        red[0][threadIdx.x >> 6] = ma;
+        red[1][threadIdx.x >> 6] = mb;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // one atomic per block and tensor (same-address atomics cost ~12 ns each); max is exact in any
+        // order.  A NaN/Inf input gives a huge pattern -> tiny scale: the result stays NaN/Inf (loud).
+        ma = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+        mb = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
         atomicMax(out + 0, __float_as_uint(ma));
         atomicMax(out + 1, __float_as_uint(mb));
     }
@@ -296,7 +305,8 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
     }
 }
 
-// dw[co][ci][kh][kw] = scale/(sa*sb) * sum_splits partial[s][t=(i,j)][p][q], p/q = (co,ci) or (ci,co)
+// dw[co][ci][kh][kw] = scale/(sa*sb) * sum_splits partial[s][t=(i,j)][p][q], p/q = (co,ci) or (ci,co).
+// Four lanes share one output (each sums every 4th partial, then a fixed-order butterfly): deterministic.
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ partial, float *__restrict__ dw,
                                                       const unsigned *__restrict__ absmax, int nsplit, int C, int KH,
                                                       int KW, int swapped, int top, int left, float scale,
@@ -305,10 +315,18 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
     const int NT = KH * KW;
     const size_t total = (size_t)NT * C * C;
     const float inv = scale / (pow2_scale(absmax[0]) * pow2_scale(absmax[1]));
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int sub = threadIdx.x >> 6;                                    // wave index = partial residue class
+    const size_t idx = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);     // output element
+    __shared__ float red[4][64];
+    float s = 0.f;
+    if (idx < total)
+        for (int k = sub; k < nsplit; k += 4) s += partial[(size_t)k * total + idx];
+    red[sub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sub == 0 && idx < total) {
+        const int l = threadIdx.x & 63;
+        s = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
         const int q = (int)(idx % C), p = (int)((idx / C) % C), t = (int)(idx / ((size_t)C * C));
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * total + idx];
         const int i = t / KW, j = t % KW;
         const int kh = top ? KH - 1 - i : i, kw = left ? KW - 1 - j : j;
         const int co = swapped ? q : p, ci = swapped ? p : q;
@@ -371,7 +389,7 @@ int launch_wgrad_mfma(const float *gz, const float *x, float *dw, void *ws, int 
     IFL_HIP(hipMemsetAsync(absmax, 0, 2 * sizeof(unsigned), s));
     {
         size_t blocks = (n / 4 + 255) / 256;
-        if (blocks > 1024) blocks = 1024;
+        if (blocks > 512) blocks = 512;
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(k_absmax2, dim3((unsigned)blocks), dim3(256), 0, s, gz, x, n, absmax);
         IFL_HIP(hipGetLastError());
@@ -397,7 +415,7 @@ int launch_wgrad_mfma(const float *gz, const float *x, float *dw, void *ws, int 
     if (rc) return rc;
     const int nsplit = (wgrad_ntask(B, H) + 3) / 4;
     const size_t total = (size_t)KH * KW * C * C;
-    size_t blocks = (total + 255) / 256;
+    size_t blocks = (total + 63) / 64;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)blocks), dim3(256), 0, s, partial, dw, absmax, nsplit, C, KH, KW,
                        swapped, top, left, scale, mask_mode, mkh, mkw);
     IFL_HIP(hipGetLastError());

@@ -5,23 +5,33 @@
 // so the sequential chain carries r only; x enters as the plain fp32 accumulator seed and
 // z = L^-1 r is a per-pixel product that is *off* the dependency chain.
 //
-// Mapping.  One workgroup per image, one wave per 16 output channels (C/16 waves).  MFMA tile =
-// 16 channels x 16 image rows: MFMA column n of tile T is image row h = 16T+n for the whole
-// kernel, and walks along w = d-h as the anti-diagonal index d advances (pixel (h,w) is on
-// diagonal h+w; every source (h-dh, w-dw) is on an earlier diagonal: solve_mc.py:88-114 in
-// diagonal order, cf. solve_parallel, solve_mc.py:8-50).  Because a lane keeps its row, its x
-// values and z results are consecutive in memory over consecutive steps: x is read and z written
-// as aligned 16-byte quads straight from/to NCHW, no staging through LDS.
+// Mapping.  One workgroup per image, one wave per 16 output channels (C/16 waves, one per SIMD).
+// MFMA tile = 16 channels x 16 image rows: MFMA column n of tile T is image row h = 16T+n for the
+// whole kernel and walks along w = d-h as the anti-diagonal index d advances (pixel (h,w) is on
+// diagonal h+w; every source (h-dh, w-dw) is on an earlier diagonal: solve_mc.py:88-114 in diagonal
+// order, cf. solve_parallel, solve_mc.py:8-50).
 //
-// LDS holds only a ring of the last KH+KW-1 diagonals of r as split fp16 (hi, lo*2^11), laid out
-// [slot][row][hi C | lo C] so that a lane's MFMA B fragment (8 consecutive channels of one pixel)
-// is one ds_read_b128.  Rows above the image and pixels left of it are never written and stay
-// zero, which is exactly the TL zero padding.
+// LDS (~151 KB at C=64, 32 rows):
+//   ring   last KH+KW-1 diagonals of r as split fp16 (hi, lo*2^11), [slot][row block][plane][row%16]
+//          16-byte pieces, plane = (k-step, hi/lo, k-group): a lane's MFMA B fragment is one
+//          ds_read_b128 and the 16 lanes of every hardware lane group hit 16 different 4-bank
+//          columns (conflict-free; the naive [row][channel] layout measured 52 % conflict cycles).
+//          Sources above the image read a zero block, pixels left of it are never written and stay
+//          zero: exactly the TL zero padding.
+//   xs     x quads [row][quad parity][channel], filled by LDS-DMA (global_load_lds_dwordx4: no VGPR
+//          destination, nothing for the compiler to track) three steps before their first use.
+//   zring  last 5 diagonals of z (fp32) [slot][row][channel]; a row's quad is stored to NCHW with one
+//          global_store_dwordx4 per channel once its four diagonals are in.
+// Both global streams move 16-byte aligned quads of one (channel, row) line; lane = channel.
+//
+// The only vector-memory operations of a wave are its own DMAs and stores, whose numbers per step are
+// known exactly, so the wait before each barrier is an exact s_waitcnt vmcnt(n): "the DMA issued three
+// steps ago has landed", never "everything, including the stores I just issued".
 //
 // Arithmetic: split-fp16 MFMA with fp32 accumulation.  a*b ~= ah*bh + (ah*bl' + al'*bh) 2^-11 with
 // ah = fp16(a), al' = fp16((a-ah) 2^11): three v_mfma_f32_16x16x32_f16 per 32-deep k-step, the
-// dropped al*bl term is 2^-22 relative.  The folded weights live in registers for the whole scan
-// (144 VGPRs at C=64, K=3).
+// dropped al*bl term is 2^-22 relative; fp16 denormal operands are kept by the MFMA (checked on
+// gfx950 with tools/mfma_f16_denorm_probe.hip).  The folded weights live in AGPRs for the whole scan.
 #include <type_traits>
 
 #include "ifl_common.h"
@@ -35,119 +45,89 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 static constexpr float LO_SCALE = 2048.0f;
 static constexpr float LO_INV = 1.0f / 2048.0f;
 
-__device__ __forceinline__ float sel4(const floatx4 &v, int i)
-{
-    float r = v[0];
-    r = i == 1 ? v[1] : r;
-    r = i == 2 ? v[2] : r;
-    r = i == 3 ? v[3] : r;
-    return r;
-}
-
-__device__ __forceinline__ void ins4(floatx4 &v, int i, float x)
-{
-    v[0] = i == 0 ? x : v[0];
-    v[1] = i == 1 ? x : v[1];
-    v[2] = i == 2 ? x : v[2];
-    v[3] = i == 3 ? x : v[3];
-}
-
 template <int C, int KH, int KW, int NTILE> struct ScanCfg {
-    static constexpr int NW = C / 16;          // compute waves = 16-channel output groups
-    static constexpr int NQ = C / 32;          // 32-deep k-steps per tap
-    static constexpr int NT = KH * KW;         // taps incl. the diagonal one
-    static constexpr int NS = NT;              // A slots: NT-1 folded taps + 1 post matrix (L^-1)
-    static constexpr int R = KH + KW - 1;      // ring depth (current + KH+KW-2 previous diagonals)
-    static constexpr int PADR = KH - 1;        // always-zero rows above the image
-    static constexpr int ROWB = 4 * C + 16;    // bytes per ring row: hi C*2 | lo C*2 | 16 pad
-    static constexpr int NROW = 16 * NTILE + PADR;
-    static constexpr int SLOTB = NROW * ROWB;
+    static constexpr int NW = C / 16;      // 16-channel output groups
+    static constexpr int NWAVES = NW * NTILE; // one wave per (row tile, channel group): two waves per SIMD at 32 rows
+    static constexpr int NQ = C / 32;      // 32-deep k-steps per tap
+    static constexpr int NT = KH * KW;     // taps incl. the diagonal one
+    static constexpr int NS = NT;          // A slots: NT-1 folded taps + 1 post matrix (L^-1)
+    static constexpr int R = KH + KW - 1;  // r-ring depth (current + KH+KW-2 previous diagonals)
+    static constexpr int NPL = NQ * 8;     // planes per row block: (k-step, hi/lo, k-group)
+    static constexpr int RBB = NPL * 256;  // bytes of one row block (16 rows x NPL planes x 16 B)
+    static constexpr int SLOTB = NTILE * RBB;
     static constexpr int RINGB = R * SLOTB;
-    // x staging: [row h][quad parity][channel] 16-byte quads, filled by the loader wave's LDS-DMA
-    static constexpr int XSB = 16 * NTILE * 2 * C * 16;
-    static constexpr int LDSB = RINGB + XSB;
-    static constexpr int THREADS = 64 * NW;
-    static constexpr int ROWS_PER_ITER = 4 * NTILE;      // rows that need their next quad each step
-    static constexpr int G = ROWS_PER_ITER / NW;         // LDS-DMA instructions per wave and step
-    static_assert(ROWS_PER_ITER % NW == 0, "rows per step must split evenly over the waves");
+    static constexpr int ZEROB = RBB;      // always-zero block read for sources above the image
+    static constexpr int XROWB = 2 * C * 16 + 16; // x quads of one row: [parity][channel] + pad
+    static constexpr int XSB = 16 * NTILE * XROWB;
+    static constexpr int RZ = 5;           // z-ring depth: a quad's 4 diagonals + the one being written
+    static constexpr int ZROWB = C * 4 + 16;
+    static constexpr int ZSLOTB = 16 * NTILE * ZROWB;
+    static constexpr int ZRINGB = RZ * ZSLOTB;
+    static constexpr int OFF_ZERO = RINGB, OFF_XS = OFF_ZERO + ZEROB, OFF_ZR = OFF_XS + XSB;
+    static constexpr int LDSB = OFF_ZR + ZRINGB;
+    static constexpr int THREADS = 64 * NWAVES;
+    static constexpr int ROWS_PER_ITER = 4 * NTILE; // rows that start/finish a quad each step
+    static constexpr int G = ROWS_PER_ITER / NWAVES; // ... per wave: DMA (and at most as many store) instructions
+    static_assert(ROWS_PER_ITER % NWAVES == 0, "rows per step must split evenly over the waves");
+    static_assert(C <= 64, "one DMA / store instruction covers one image row of all channels (lane = channel)");
+    static_assert(KH <= 16, "a source row is at most one row block up");
 };
 
-// x staging.  Every step each wave issues G global_load_lds_dwordx4 (LDS-DMA: no VGPR destination,
-// nothing for the compiler to track): for a row h that is one step into a quad (w = d-h = 1 mod 4) it
-// brings the *next* quad x[:, h, w+3 .. w+6] of all C channels (lane = channel) into the slot
-// [h][quad parity].  The quad is first read 3 steps later.  Its slot-mate (two quads back) was read for
-// the last time in phase C of step d-2, which every wave left before the barrier of step d-1, so the
-// DMA cannot overwrite data that is still being read.
-template <int C, int KH, int KW, int NTILE>
-__device__ __forceinline__ void scan_issue_dma(const float *__restrict__ xin, unsigned char *xs, int b, int wv, int lane,
-                                               int d, int H, int W, int rh, int rw)
+// LDS fragment read / counted wait as inline asm: hipcc's own waitcnt insertion answers a block of
+// outstanding ds_reads with lgkmcnt(0) (measured: every prefetched fragment waited for the youngest one),
+// so the fragment pipeline is counted by hand.  LDS operations of a wave complete in order; the wait
+// statement redefines the fragments it guards, which keeps their MFMAs behind it.
+__device__ __forceinline__ void lds_read_b128(half8 &v, unsigned addr)
 {
-    using Cfg = ScanCfg<C, KH, KW, NTILE>;
-    static_assert(C <= 64, "one LDS-DMA instruction covers one image row of all channels");
-    const int c = lane < C ? lane : 0;
-    const int ph = (((d - 1) % 4) + 4) % 4;
-#pragma unroll
-    for (int i = 0; i < Cfg::G; ++i) {
-        const int h = ph + 4 * (wv * Cfg::G + i);
-        const int wq = d - h + 3; // first column of the next quad of that row
-        const int qslot = (wq >> 2) & 1;
-        // out-of-range rows / quads: load something valid into the slot, nobody reads it -- the
-        // instruction is issued unconditionally so that the number of VM operations per step is exact
-        const bool ok = h < H && wq >= 0 && wq < W;
-        const int hc = ok ? h : 0, wc = ok ? wq : 0;
-        const int hs = rh ? H - 1 - hc : hc;
-        const int ws = rw ? W - 4 - wc : wc;
-        const float *src = xin + (((size_t)b * C + c) * H + hs) * W + ws;
-        unsigned char *dst = xs + (size_t)((h * 2 + qslot) * C) * 16; // wave-uniform; lane c lands at +16c
-        if (C == 64 || lane < C)
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)src,
-                                             (void __attribute__((address_space(3))) *)dst, 16, 0, 0);
-    }
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+}
+template <int N> __device__ __forceinline__ void lgkm_wait(half8 &a, half8 &b)
+{
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
 }
 
 // "all but the n youngest vector-memory operations of this wave are complete", LDS drained, then the
-// workgroup barrier.  n is exact (see the step body), so the wave never waits for anything younger than
-// the DMA it needs -- in particular not for its own recent z stores, which share the same counter.
+// workgroup barrier.  n is exact (see the step body) and wave-uniform.
 __device__ __forceinline__ void wait_vm_then_barrier(int n)
 {
 #define IFL_W(N) \
     case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-    switch (n) {
+    switch (__builtin_amdgcn_readfirstlane(n)) {
         IFL_W(0) IFL_W(1) IFL_W(2) IFL_W(3) IFL_W(4) IFL_W(5) IFL_W(6) IFL_W(7) IFL_W(8) IFL_W(9) IFL_W(10) IFL_W(11)
         IFL_W(12) IFL_W(13) IFL_W(14) IFL_W(15) IFL_W(16) IFL_W(17) IFL_W(18) IFL_W(19) IFL_W(20) IFL_W(21) IFL_W(22)
-        IFL_W(23) IFL_W(24) IFL_W(25) IFL_W(26) IFL_W(27) IFL_W(28) IFL_W(29) IFL_W(30) IFL_W(31) IFL_W(32) IFL_W(33)
-        IFL_W(34) IFL_W(35) IFL_W(36) IFL_W(37) IFL_W(38) IFL_W(39) IFL_W(40) IFL_W(41) IFL_W(42) IFL_W(43) IFL_W(44)
-        IFL_W(45) IFL_W(46) IFL_W(47) IFL_W(48)
+        IFL_W(23) IFL_W(24)
     default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
     }
 #undef IFL_W
 }
 
 template <int C, int KH, int KW, int NTILE>
-__global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__restrict__ xin,
-                                                                 float *__restrict__ zout,
-                                                                 const half8 *__restrict__ apack, int H, int W, int rh,
-                                                                 int rw)
+__global__ __launch_bounds__(64 * (C / 16) * NTILE) void k_scan_mfma(const float *__restrict__ xin,
+                                                                    float *__restrict__ zout,
+                                                                    const half8 *__restrict__ apack, int H, int W,
+                                                                    int rh, int rw)
 {
     using Cfg = ScanCfg<C, KH, KW, NTILE>;
-    constexpr int NQ = Cfg::NQ, NT = Cfg::NT, NS = Cfg::NS, R = Cfg::R, PADR = Cfg::PADR, ROWB = Cfg::ROWB,
-                  SLOTB = Cfg::SLOTB;
+    constexpr int NQ = Cfg::NQ, NT = Cfg::NT, NS = Cfg::NS, R = Cfg::R, RBB = Cfg::RBB, SLOTB = Cfg::SLOTB,
+                  RZ = Cfg::RZ, G = Cfg::G, NW = Cfg::NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char *ring = lds;
-    unsigned char *xs = lds + Cfg::RINGB;
+    unsigned char *xs = lds + Cfg::OFF_XS;
+    unsigned char *zr = lds + Cfg::OFF_ZR;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index: scalar
+    const int wv = wave % NW; // 16-channel output group of this wave
+    const int T = wave / NW;  // 16-row tile of this wave
     const int n = lane & 15, g = lane >> 4;
     const int b = blockIdx.x;
     const int ND = H + W - 1;
 
-    // ---- zero the ring (zero padding of the operator) ------------------------------------------------
+    // ---- zero the r-ring and the zero block (zero padding of the operator) ---------------------------
     {
         const floatx4 zz = {0.f, 0.f, 0.f, 0.f};
-        for (int i = tid * 16; i < Cfg::RINGB; i += Cfg::THREADS * 16) *(floatx4 *)(ring + i) = zz;
+        for (int i = tid * 16; i < Cfg::OFF_XS; i += Cfg::THREADS * 16) *(floatx4 *)(lds + i) = zz;
     }
-    __syncthreads();
 
     // ---- folded weights -> registers (A fragments, hi and lo) -----------------------------------
     half8 A[NS][NQ][2];
@@ -164,225 +144,286 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
             }
 
     // ---- per-lane constants -------------------------------------------------------------------
-    const int c0 = 16 * wv + 4 * g; // first of this lane's 4 output channels (C/D layout rows)
-    int hrow[NTILE];                // image row of this lane in tile T
-    bool hval[NTILE];
-    size_t gbase[NTILE];            // element offset of (b, c0, stored row, 0)
-    int rbase[NTILE];               // LDS byte offset of (row h, k-group g) inside a slot
-    int wbase[NTILE];               // LDS byte offset of this lane's 4 hi halves inside a slot
-    int xbase[NTILE];               // LDS byte offset of this lane's first x quad (row h, parity 0, channel c0)
-    floatx4 zo[NTILE][4];
+    // compute role: lane (n, g) owns pixel row h = 16T+n and channels c0..c0+3 (C/D layout)
+    const int c0 = 16 * wv + 4 * g;
+    const int h = 16 * T + n;
+    const bool hval = h < H;
+    int radr[KH]; // slot-relative LDS offset of this lane's B piece for a source dh rows up (plane 0 of its g)
+    bool rzero[KH]; // the source row is above the image
 #pragma unroll
-    for (int T = 0; T < NTILE; ++T) {
-        hrow[T] = 16 * T + n;
-        hval[T] = hrow[T] < H;
-        const int hs = rh ? H - 1 - hrow[T] : hrow[T];
-        gbase[T] = (((size_t)b * C + c0) * H + (hval[T] ? hs : 0)) * W;
-        rbase[T] = (hrow[T] + PADR) * ROWB + g * 16;
-        wbase[T] = (hrow[T] + PADR) * ROWB + c0 * 2;
-        xbase[T] = ((hrow[T] * 2) * C + c0) * 16;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) zo[T][r] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int dh = 0; dh < KH; ++dh) {
+        const int hs = h - dh;
+        rzero[dh] = hs < 0;
+        radr[dh] = hs >= 0 ? (hs / 16) * RBB + g * 256 + (hs % 16) * 16 : 0;
     }
-    const size_t cstride = (size_t)H * W;
+    const int wadr = T * RBB + (((c0 / 32) * 2) * 4 + (c0 % 32) / 8) * 256 + n * 16 + ((c0 % 8) / 4) * 8;
+    const int xadr = h * Cfg::XROWB + c0 * 16;
+    const int zadr = h * Cfg::ZROWB + c0 * 4;
+    const int zbase = Cfg::OFF_ZERO + g * 256 + n * 16; // this lane's piece in the zero block
+    const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
 
-    // soff[k] = LDS byte offset of the slot holding diagonal d-k
-    int soff[R];
+    // DMA / store role: lane = channel, G rows per wave and step
+    const int cl = lane < C ? lane : 0;
+    const unsigned voff = (unsigned)((size_t)cl * H * W * sizeof(float)); // per-lane byte offset of its channel
+    const char *xg = (const char *)xin + (size_t)b * C * H * W * sizeof(float);
+    char *zg = (char *)zout + (size_t)b * C * H * W * sizeof(float);
+
+    // soff[k] / zoff[k]: LDS offsets of the slots holding diagonal d-k (r) and d-1-k (z)
+    int soff[R], zoff[RZ];
 #pragma unroll
     for (int k = 0; k < R; ++k) soff[k] = ((R - k) % R) * SLOTB;
-
+#pragma unroll
+    for (int k = 0; k < RZ; ++k) zoff[k] = ((RZ - k) % RZ) * Cfg::ZSLOTB;
     int nst[3] = {0, 0, 0}; // store instructions this wave issued in the previous three steps
 
-    // One step of the scan, specialised on the set of active tiles (bit T of MASK) so that its body is
-    // straight-line code: the LDS fragment reads are software-pipelined one (tap, k-step) unit ahead of
-    // the MFMAs that consume them and the tiles are interleaved, which keeps the matrix pipe fed from a
-    // single wave per SIMD.
-    auto step = [&](auto mask_c, const int d) {
-        constexpr int MASK = decltype(mask_c)::value;
-        floatx4 ahi[NTILE], amid[NTILE];
+    __syncthreads();
+
+    // One step of the scan, specialised on whether this wave's tile holds pixels of diagonal d, so that
+    // the body is straight-line code; LDS fragment reads run one (tap, k-step) unit ahead of the MFMAs
+    // that consume them.  With 32 image rows two waves share a SIMD (one per row tile): one wave's LDS
+    // latency is covered by the other's MFMAs.
+    auto step = [&](auto act_c, const int d) {
+        constexpr bool ACT = decltype(act_c)::value;
+        const int ph = (((d - 1) % 4) + 4) % 4; // rows h = ph (mod 4) are one step into a quad of x
+
+        // ---- x quads needed three steps from now: rows at w = d-h = 1 (mod 4) fetch their next quad.
+        //      The slot-mate (two quads back) was last read in phase C of step d-2, which every wave
+        //      left before the barrier of step d-1.  Issued unconditionally (out-of-range rows load a
+        //      valid dummy) so that the number of VM operations per step is exact.
 #pragma unroll
-        for (int T = 0; T < NTILE; ++T) {
-            ahi[T] = floatx4{0.f, 0.f, 0.f, 0.f};
-            amid[T] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < G; ++i) {
+            const int hr = ph + 4 * (wave * G + i);
+            const int wq = d - hr + 3;
+            const bool ok = hr < H && wq >= 0 && wq < W;
+            const int hc = ok ? hr : 0, wc = ok ? wq : 0;
+            const int hs = rh ? H - 1 - hc : hc;
+            const int ws = rw ? W - 4 - wc : wc;
+            const char *src = xg + ((size_t)hs * W + ws) * sizeof(float); // wave-uniform
+            unsigned char *dst = xs + hr * Cfg::XROWB + ((wq >> 2) & 1) * (C * 16); // lane c lands at +16c
+            if (C == 64 || lane < C)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + voff),
+                                                 (void __attribute__((address_space(3))) *)dst, 16, 0, 0);
         }
-        half8 fh[2][NTILE], fl[2][NTILE];
 
-        // x quads needed three steps from now
-        scan_issue_dma<C, KH, KW, NTILE>(xin, xs, b, wv, lane, d, H, W, rh, rw);
+        floatx4 ahi = {0.f, 0.f, 0.f, 0.f}, amid = {0.f, 0.f, 0.f, 0.f};
 
-        // unit u of a phase = (tap, k-step); SEL: 0 -> taps two or more diagonals back, 1 -> the two
-        // taps on diagonal d-1
-        auto run_phase = [&](auto sel_c) {
-            constexpr int SEL = decltype(sel_c)::value;
-            constexpr int NU = []() {
-                int c = 0;
-                for (int t = 1; t < NT; ++t) {
-                    const int s2 = t / KW + t % KW;
-                    if (SEL ? s2 == 1 : s2 >= 2) c += NQ;
-                }
-                return c;
-            }();
-            auto unit_tap = [](int u) {
-                int c = 0;
-                for (int t = 1; t < NT; ++t) {
-                    const int s2 = t / KW + t % KW;
-                    if (SEL ? s2 == 1 : s2 >= 2) {
-                        if (u < c + NQ) return t;
-                        c += NQ;
-                    }
-                }
-                return 1;
-            };
-            auto unit_q = [](int u) {
-                int c = 0;
-                for (int t = 1; t < NT; ++t) {
-                    const int s2 = t / KW + t % KW;
-                    if (SEL ? s2 == 1 : s2 >= 2) {
-                        if (u < c + NQ) return u - c;
-                        c += NQ;
-                    }
-                }
-                return 0;
-            };
-            auto load_unit = [&](int u, int buf) {
-                const int t = unit_tap(u), q = unit_q(u), dh = t / KW, dw = t % KW;
-#pragma unroll
-                for (int T = 0; T < NTILE; ++T)
-                    if (MASK & (1 << T)) {
-                        const unsigned char *rowp = ring + soff[dh + dw] + rbase[T] - dh * ROWB + q * 64;
-                        fh[buf][T] = *(const half8 *)(rowp);
-                        fl[buf][T] = *(const half8 *)(rowp + 2 * C);
-                    }
-            };
-            if constexpr (NU > 0) {
-                load_unit(0, 0);
-#pragma unroll
-                for (int u = 0; u < NU; ++u) {
-                    if (u + 1 < NU) load_unit(u + 1, (u + 1) & 1);
-                    const int t = unit_tap(u), q = unit_q(u);
-#pragma unroll
-                    for (int T = 0; T < NTILE; ++T)
-                        if (MASK & (1 << T)) {
-                            ahi[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], fh[u & 1][T], ahi[T], 0, 0, 0);
-                            amid[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], fl[u & 1][T], amid[T], 0, 0, 0);
-                            amid[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][1], fh[u & 1][T], amid[T], 0, 0, 0);
-                        }
+        // (tap, k-step) units of a phase.  SEL 0: taps two or more diagonals back (no dependence on step
+        // d-1), SEL 1: the two taps on diagonal d-1.
+        auto unit_count = [](int sel) {
+            int c = 0;
+            for (int t = 1; t < NT; ++t) {
+                const int s2 = t / KW + t % KW;
+                if (sel ? s2 == 1 : s2 >= 2) c += NQ;
+            }
+            return c;
+        };
+        auto unit_tap = [](int sel, int u) {
+            int c = 0;
+            for (int t = 1; t < NT; ++t) {
+                const int s2 = t / KW + t % KW;
+                if (sel ? s2 == 1 : s2 >= 2) {
+                    if (u < c + NQ) return t;
+                    c += NQ;
                 }
             }
+            return 1;
+        };
+        auto unit_q = [](int sel, int u) {
+            int c = 0;
+            for (int t = 1; t < NT; ++t) {
+                const int s2 = t / KW + t % KW;
+                if (sel ? s2 == 1 : s2 >= 2) {
+                    if (u < c + NQ) return u - c;
+                    c += NQ;
+                }
+            }
+            return 0;
+        };
+        auto load_frag = [&](int sel, int u, half8 &vh, half8 &vl) {
+            const int t = unit_tap(sel, u), q = unit_q(sel, u), dh = t / KW, dw = t % KW;
+            int a = soff[dh + dw] + radr[dh];
+            if (dh > 0) a = rzero[dh] ? zbase : a;
+            lds_read_b128(vh, ldsbase + a + (q * 2) * 4 * 256);
+            lds_read_b128(vl, ldsbase + a + (q * 2 + 1) * 4 * 256);
+        };
+        auto mfma3 = [&](int sel, int u, const half8 &vh, const half8 &vl) {
+            const int t = unit_tap(sel, u), q = unit_q(sel, u);
+            ahi = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], vh, ahi, 0, 0, 0);
+            amid = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], vl, amid, 0, 0, 0);
+            amid = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][1], vh, amid, 0, 0, 0);
         };
 
-        // ---- (B) taps whose sources are two or more diagonals back: no dependence on step d-1 ----
-        run_phase(std::integral_constant<int, 0>{});
+        // ---- (B) old taps: a PF-deep register ring of fragments keeps the LDS latency (a few hundred
+        //      cycles with eight waves reading) off the MFMA stream -------------------------------------
+        constexpr int NUB = unit_count(0), NUC = unit_count(1);
+        constexpr int PF = NUB < 6 ? (NUB > 0 ? NUB : 1) : 6;
+        if constexpr (ACT && NUB > 0) {
+            half8 fh[PF], fl[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) load_frag(0, u, fh[u], fl[u]);
+            // hipcc's scheduler otherwise sinks every read down to its first use (no prefetch at all):
+            // pin the source order of reads and MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < NUB; ++u) {
+                // reads issued so far: units < min(NUB, u+PF); unit u is the oldest outstanding one
+                {
+                    const int issued = (u + PF < NUB ? u + PF : NUB);
+                    const int allow = 2 * (issued - u - 1);
+                    switch (allow) {
+                    case 0: lgkm_wait<0>(fh[u % PF], fl[u % PF]); break;
+                    case 2: lgkm_wait<2>(fh[u % PF], fl[u % PF]); break;
+                    case 4: lgkm_wait<4>(fh[u % PF], fl[u % PF]); break;
+                    case 6: lgkm_wait<6>(fh[u % PF], fl[u % PF]); break;
+                    case 8: lgkm_wait<8>(fh[u % PF], fl[u % PF]); break;
+                    default: lgkm_wait<10>(fh[u % PF], fl[u % PF]); break;
+                    }
+                }
+                mfma3(0, u, fh[u % PF], fl[u % PF]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (u + PF < NUB) {
+                    load_frag(0, u + PF, fh[u % PF], fl[u % PF]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
 
         // The quads this wave DMA'd three steps ago must have landed before anyone reads them in phase C:
         // younger than those are exactly the stores of steps d-3..d-1 and the DMAs of steps d-2..d.
-        // Then the barrier: r of diagonal d-1 is complete in the ring.
-        wait_vm_then_barrier(3 * Cfg::G + nst[0] + nst[1] + nst[2]);
+        // Then the barrier: r of diagonal d-1 (and z of diagonal d-2) are complete in LDS.
+        wait_vm_then_barrier(3 * G + nst[0] + nst[1] + nst[2]);
 
-        // ---- (C) x of this step, the two taps on diagonal d-1 ---------------------------------------
-        float xv[NTILE][4];
+        // ---- (C) the two taps on diagonal d-1: all their fragments are requested at once, the MFMAs follow
+        //      with exact counted waits ---------------------------------------------------------------------
+        const int w = d - h;
+        if constexpr (ACT && NUC > 0) {
+            half8 ch[NUC], cl2[NUC];
 #pragma unroll
-        for (int T = 0; T < NTILE; ++T)
-            if (MASK & (1 << T)) {
-                const int w = d - hrow[T];
-                // this lane's 4 x values: quad (w>>2) of row h, channels c0..c0+3, element w&3
-                const unsigned char *xp = xs + xbase[T] + ((w >> 2) & 1) * (C * 16) + (rw ? 3 - (w & 3) : (w & 3)) * 4;
+            for (int u = 0; u < NUC; ++u) load_frag(1, u, ch[u], cl2[u]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xv[T][r] = *(const float *)(xp + r * 16);
+            for (int u = 0; u < NUC; ++u) {
+                switch (2 * (NUC - 1 - u)) {
+                case 0: lgkm_wait<0>(ch[u], cl2[u]); break;
+                case 2: lgkm_wait<2>(ch[u], cl2[u]); break;
+                case 4: lgkm_wait<4>(ch[u], cl2[u]); break;
+                case 6: lgkm_wait<6>(ch[u], cl2[u]); break;
+                case 8: lgkm_wait<8>(ch[u], cl2[u]); break;
+                case 10: lgkm_wait<10>(ch[u], cl2[u]); break;
+                default: lgkm_wait<0>(ch[u], cl2[u]); break;
+                }
+                mfma3(1, u, ch[u], cl2[u]);
             }
-        run_phase(std::integral_constant<int, 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
 
-        // ---- (D) z of diagonal d-1 = L^-1 r: independent MFMAs issued before the epilogue's VALU work so
-        //      that the matrix pipe stays busy while r_d is converted and written ----------------------
-        floatx4 zh[NTILE], zm[NTILE];
-        bool actz[NTILE];
+        // ---- requests whose latency hides behind the MFMAs just issued: x of this step, the fragments of
+        //      the z product, the finished z quad(s) --------------------------------------------------------
+        float xv[4];
+        if constexpr (ACT) {
+            // this lane's 4 x values: quad (w>>2) of row h, channels c0..c0+3, element w&3
+            const unsigned char *xp = xs + xadr + ((w >> 2) & 1) * (C * 16) + (rw ? 3 - (w & 3) : (w & 3)) * 4;
 #pragma unroll
-        for (int T = 0; T < NTILE; ++T) {
-            actz[T] = d - 1 >= 16 * T && d - 1 <= 16 * T + 15 + W - 1 && d >= 1 && 16 * T < H;
-            zh[T] = floatx4{0.f, 0.f, 0.f, 0.f};
-            zm[T] = floatx4{0.f, 0.f, 0.f, 0.f};
-            if (actz[T]) {
-                const unsigned char *rowp = ring + soff[1] + rbase[T];
-                half8 bh[NQ], bl[NQ];
+            for (int r = 0; r < 4; ++r) xv[r] = *(const float *)(xp + r * 16);
+        }
+        const bool actz = d - 1 >= 16 * T && d - 1 <= 16 * T + 15 + W - 1 && d >= 1 && d <= ND && 16 * T < H;
+        half8 bh[NQ], bl[NQ];
+        if (actz) {
+            const unsigned char *pp = lds + soff[1] + radr[0];
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    bh[q] = *(const half8 *)(rowp + q * 64);
-                    bl[q] = *(const half8 *)(rowp + 2 * C + q * 64);
-                }
+            for (int q = 0; q < NQ; ++q) {
+                bh[q] = *(const half8 *)(pp + (q * 2) * 4 * 256);
+                bl[q] = *(const half8 *)(pp + (q * 2 + 1) * 4 * 256);
+            }
+        }
+        // store role: rows h = ph (mod 4) completed a quad of z with diagonal d-2; its four elements sit
+        // in the z-slots of diagonals d-5..d-2 (zoff[k] holds diagonal d-1-k)
+        floatx4 sv[G];
+        bool sok[G];
+        int nstore = 0;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    zh[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[NS - 1][q][0], bh[q], zh[T], 0, 0, 0);
-                    zm[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[NS - 1][q][0], bl[q], zm[T], 0, 0, 0);
-                    zm[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[NS - 1][q][1], bh[q], zm[T], 0, 0, 0);
-                }
+        for (int i = 0; i < G; ++i) {
+            const int hr = ph + 4 * (wave * G + i);
+            const int w3 = d - 2 - hr; // last column of the quad (w3 = 3 mod 4)
+            sok[i] = hr < H && w3 >= 3 && w3 < W; // wave-uniform
+            if (sok[i]) {
+                nstore += 1;
+                const unsigned char *zp = zr + hr * Cfg::ZROWB + cl * 4;
+                sv[i][rw ? 3 : 0] = *(const float *)(zp + zoff[4]);
+                sv[i][rw ? 2 : 1] = *(const float *)(zp + zoff[3]);
+                sv[i][rw ? 1 : 2] = *(const float *)(zp + zoff[2]);
+                sv[i][rw ? 0 : 3] = *(const float *)(zp + zoff[1]);
             }
         }
 
-        // ---- epilogue: r_d -> split fp16 -> ring ---------------------------------------------------------
+        // ---- (D) z of diagonal d-1 = L^-1 r: independent MFMAs that keep the matrix pipe busy while r_d is
+        //      converted and written ---------------------------------------------------------------------
+        floatx4 zh = {0.f, 0.f, 0.f, 0.f}, zm = {0.f, 0.f, 0.f, 0.f};
+        if (actz) {
 #pragma unroll
-        for (int T = 0; T < NTILE; ++T)
-            if (MASK & (1 << T)) {
-                const int w = d - hrow[T];
-                half4 hi, lo;
+            for (int q = 0; q < NQ; ++q) {
+                zh = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[NS - 1][q][0], bh[q], zh, 0, 0, 0);
+                zm = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[NS - 1][q][0], bl[q], zm, 0, 0, 0);
+                zm = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[NS - 1][q][1], bh[q], zm, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0); // MFMAs are in the pipe before the VALU-heavy tail starts
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float rv = xv[T][r] + ahi[T][r] + amid[T][r] * LO_INV;
-                    const _Float16 h16 = (_Float16)rv;
-                    hi[r] = h16;
-                    lo[r] = (_Float16)((rv - (float)h16) * LO_SCALE);
-                }
-                if (hval[T] && w >= 0 && w < W) {
-                    *(half4 *)(ring + soff[0] + wbase[T]) = hi;
-                    *(half4 *)(ring + soff[0] + wbase[T] + 2 * C) = lo;
-                }
+        for (int i = 0; i < G; ++i)
+            if (sok[i]) {
+                const int hr = ph + 4 * (wave * G + i);
+                const int w3 = d - 2 - hr;
+                const int hs = rh ? H - 1 - hr : hr;
+                const int ws = rw ? W - 1 - w3 : w3 - 3;
+                char *dstp = zg + ((size_t)hs * W + ws) * sizeof(float); // wave-uniform
+                if (C == 64 || lane < C) *(floatx4 *)(dstp + voff) = sv[i];
             }
 
-        // ---- z quads: gather, store when a quad is complete -----------------------------------------
-        int nstore = 0; // exact number of store instructions this wave issues in this step
+        // ---- epilogue: r_d -> split fp16 -> ring; z_{d-1} -> z-ring ----------------------------------------
+        if constexpr (ACT) {
+            half4 hi, lo;
 #pragma unroll
-        for (int T = 0; T < NTILE; ++T)
-            if (actz[T]) {
-                const int wz = d - 1 - hrow[T];
-                const int phz = rw ? 3 - (wz & 3) : (wz & 3);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ins4(zo[T][r], phz, zh[T][r] + zm[T][r] * LO_INV);
-                const bool st = hval[T] && wz >= 0 && wz < W && (wz & 3) == 3;
-                if (__builtin_amdgcn_ballot_w64(st) != 0) { // wave-uniform: the stores below are issued
-                    nstore += 4;
-                    if (st) {
-                        const int ws = rw ? W - 1 - wz : wz - 3;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) *(floatx4 *)(zout + gbase[T] + r * cstride + ws) = zo[T][r];
-                    }
-                }
+            for (int r = 0; r < 4; ++r) {
+                const float rv = xv[r] + ahi[r] + amid[r] * LO_INV;
+                const _Float16 h16 = (_Float16)rv;
+                hi[r] = h16;
+                lo[r] = (_Float16)((rv - (float)h16) * LO_SCALE);
             }
-        nst[2] = nst[1];
-        nst[1] = nst[0];
-        nst[0] = nstore;
+            if (hval && w >= 0 && w < W) {
+                *(half4 *)(ring + soff[0] + wadr) = hi;
+                *(half4 *)(ring + soff[0] + wadr + 4 * 256) = lo;
+            }
+        }
+        if (actz) {
+            floatx4 zv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zv[r] = zh[r] + zm[r] * LO_INV;
+            *(floatx4 *)(zr + zoff[0] + zadr) = zv; // lanes outside the image write values nobody stores
+        }
 
-        // rotate the slot table: diagonal d+1 takes the slot of diagonal d-(R-1)
+        // rotate the slot tables: diagonal d+1 takes the slot of diagonal d-(R-1), likewise for z
         {
             const int last = soff[R - 1];
 #pragma unroll
             for (int k = R - 1; k > 0; --k) soff[k] = soff[k - 1];
             soff[0] = last;
+            const int zlast = zoff[RZ - 1];
+#pragma unroll
+            for (int k = RZ - 1; k > 0; --k) zoff[k] = zoff[k - 1];
+            zoff[0] = zlast;
         }
+        nst[2] = nst[1];
+        nst[1] = nst[0];
+        nst[0] = nstore;
     };
 
-    for (int d = -4; d <= ND; ++d) {
-        int mask = 0;
-#pragma unroll
-        for (int T = 0; T < NTILE; ++T)
-            // wave-uniform: does tile T hold any pixel of diagonal d?
-            if (d >= 16 * T && d <= 16 * T + 15 + W - 1 && d < ND && 16 * T < H) mask |= 1 << T;
-        if (NTILE == 2 && mask == 3)
-            step(std::integral_constant<int, (NTILE == 2 ? 3 : 1)>{}, d);
-        else if (NTILE == 2 && mask == 2)
-            step(std::integral_constant<int, (NTILE == 2 ? 2 : 1)>{}, d);
-        else if (mask == 1)
-            step(std::integral_constant<int, 1>{}, d);
+    for (int d = -3; d <= ND + 1; ++d) {
+        // wave-uniform: does this wave's tile hold any pixel of diagonal d?
+        const bool act = d >= 16 * T && d <= 16 * T + 15 + W - 1 && d < ND && 16 * T < H;
+        if (act)
+            step(std::true_type{}, d);
         else
-            step(std::integral_constant<int, 0>{}, d);
+            step(std::false_type{}, d);
     }
 }
 

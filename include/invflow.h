@@ -63,7 +63,7 @@ const char *ifl_last_error(void);
  * hipEvents on the caller's stream; ifl_profile_collect() waits for them, returns the summed
  * device milliseconds and the launch count for `tag`, and forgets them.
  */
-enum { IFL_PROF_SCAN = 0, IFL_PROF_WGRAD = 1, IFL_PROF_CONV = 2, IFL_PROF_FOLD = 3 };
+enum { IFL_PROF_SCAN = 0, IFL_PROF_WGRAD = 1, IFL_PROF_CONV = 2, IFL_PROF_FOLD = 3, IFL_PROF_FALLBACK = 4 };
 void ifl_profile_enable(int on);
 int ifl_profile_collect(int tag, double *total_ms, int *launches);
 

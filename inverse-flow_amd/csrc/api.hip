@@ -84,9 +84,10 @@ static int check_shape(const char *fn, int B, int C, int H, int W, int KH, int K
     return IFL_OK;
 }
 
-static size_t fold_bytes(int C, int KH, int KW)
+static size_t fold_bytes(int B, int C, int KH, int KW)
 {
-    return align_up((size_t)C * C * sizeof(double), 256) + align_up((size_t)KH * KW * C * C * sizeof(float), 256) + 512;
+    return align_up((size_t)C * C * sizeof(double), 256) + 2 * align_up((size_t)KH * KW * C * C * sizeof(float), 256) +
+           align_up(((size_t)B + 1) * sizeof(int), 256) + 1024;
 }
 
 // fold + scan (shared by inverse and dx): z = scan(x) for the operator or its adjoint.
@@ -95,22 +96,27 @@ static int run_scan(const float *x, const float *w, float *z, const Geom &g, int
 {
     double *linv = cv.take<double>((size_t)g.C * g.C);
     float *wf = cv.take<float>((size_t)g.KH * g.KW * g.C * g.C); // folded taps (fp32) or packed fp16 hi/lo fragments
+    float *wf2 = cv.take<float>((size_t)g.KH * g.KW * g.C * g.C); // fp32 left fold of the overflow fallback
+    int *ovf = cv.take<int>((size_t)g.B + 1);                    // per-image + any overflow flags of the MFMA scan
     if (!cv.ok()) IFL_FAIL(IFL_EWORKSPACE, "workspace too small: need %zu bytes, have %zu", cv.off, cv.cap);
     int rc;
     const int rh = g.flipH ^ (transposed ? 1 : 0), rw = g.flipW ^ (transposed ? 1 : 0);
     const bool mfma = !(flags & (IFL_FLAG_NO_MFMA | IFL_FLAG_EXACT_F32)) && scan_mfma_supported(g, x, z);
+    if (mfma) {
+        {
+            ProfScope ps(IFL_PROF_FOLD, s);
+            if ((rc = launch_foldpack_mfma(w, wf, wf2, g, transposed, 0, ovf, s))) return rc;
+        }
+        // (an image whose r leaves the fp16 range is redone in exact fp32 inside the same launch, from wf2)
+        ProfScope ps(IFL_PROF_SCAN, s);
+        return launch_scan_mfma(x, wf, z, g, rh, rw, ovf, wf2, s);
+    }
     {
         ProfScope ps(IFL_PROF_FOLD, s);
-        if (mfma) {
-            rc = launch_foldpack_mfma(w, wf, g, transposed, s);
-        } else {
-            if ((rc = launch_linv(w, linv, g, s))) return rc;
-            rc = launch_fold(w, linv, wf, g, transposed, s);
-        }
-        if (rc) return rc;
+        if ((rc = launch_linv(w, linv, g, s))) return rc;
+        if ((rc = launch_fold(w, linv, wf, g, transposed, s))) return rc;
     }
     ProfScope ps(IFL_PROF_SCAN, s);
-    if (mfma) return launch_scan_mfma(x, wf, z, g, rh, rw, s);
     return launch_scan_general(x, wf, z, g, rh, rw, s);
 }
 
@@ -170,12 +176,12 @@ size_t ifl_workspace_bytes(int op, int B, int C, int H, int W, int KH, int KW, u
     switch (op) {
     case IFL_OP_INVERSE:
     case IFL_OP_DY:
-        return fold_bytes(C, KH, KW);
+        return fold_bytes(B, C, KH, KW);
     case IFL_OP_FORWARD:
         return wbytes;
     case IFL_OP_BACKWARD:
         // fold + (dx when the caller passes none) + (A z and mixed gradient for the recon term) + dW partials
-        return fold_bytes(C, KH, KW) + wbytes + 3 * n + wgrad_mfma_workspace_bytes(B, C, H, KH, KW) + 512;
+        return fold_bytes(B, C, KH, KW) + wbytes + 3 * n + wgrad_mfma_workspace_bytes(B, C, H, KH, KW) + 512;
     case IFL_OP_DW:
         return wgrad_mfma_workspace_bytes(B, C, H, KH, KW) + 512;
     default:

@@ -66,8 +66,12 @@ int launch_recon_mix(const float *dx, const float *x, const float *az, float *t,
 // ---- MFMA scan (scan_mfma.hip): C in {32,64}, K in {2x2,3x3}, H <= 32, W % 4 == 0 -----------------
 bool scan_mfma_supported(const Geom &g, const void *x, const void *z);
 size_t scan_mfma_pack_bytes(const Geom &g);
-int launch_foldpack_mfma(const float *w, void *apack, const Geom &g, int transposed, hipStream_t s);
-int launch_scan_mfma(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, hipStream_t s);
+// mode 0: packed split-fp16 A fragments of the right fold (also zeroes the B overflow flags + the any-flag);
+// mode 1: fp32 left fold wf[t][kc][c] for the general scan, skipped unless *gate_any != 0 (overflow fallback)
+int launch_foldpack_mfma(const float *w, void *out, float *wf32, const Geom &g, int transposed, int mode, int *flags,
+                         hipStream_t s);
+int launch_scan_mfma(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, int *flags,
+                     const float *wf32, hipStream_t s);
 
 // ---- MFMA weight gradient (wgrad_mfma.hip): C in {32,64}, W in {16,32}, K in {2x2,3x3}, corner pads ----
 bool wgrad_mfma_supported(int B, int C, int H, int W, int KH, int KW, int pt, int pl, const void *gz, const void *x);
@@ -78,7 +82,8 @@ int launch_wgrad_mfma(const float *gz, const float *x, float *dw, void *ws, int 
 // ---- general (any C, any K) VALU kernels (scan_general.hip, conv_general.hip) ----------------
 size_t scan_general_lds_bytes(const Geom &g);
 // z = scan(x) with folded taps wf; pixel reflection (rh, rw) applied to both x and z addressing.
-int launch_scan_general(const float *x, const float *wf, float *z, const Geom &g, int rh, int rw, hipStream_t s);
+int launch_scan_general(const float *x, const float *wf, float *z, const Geom &g, int rh, int rw, hipStream_t s,
+                        const int *gate = nullptr, int rf = 0);
 
 // out[b][co][oh][ow] = bias[co] + sum w[co][ci][kh][kw] * in[b][ci][oh-pt+kh][ow-pl+kw]
 int launch_conv_direct(const float *in, const float *w, const float *bias, float *out, int B, int Ci, int Co,

@@ -35,6 +35,7 @@
 #include <type_traits>
 
 #include "ifl_common.h"
+#include "scan_general_body.h"
 
 namespace ifl {
 
@@ -105,7 +106,8 @@ template <int C, int KH, int KW, int NTILE>
 __global__ __launch_bounds__(64 * (C / 16) * NTILE) void k_scan_mfma(const float *__restrict__ xin,
                                                                     float *__restrict__ zout,
                                                                     const half8 *__restrict__ apack, int H, int W,
-                                                                    int rh, int rw)
+                                                                    int rh, int rw, int *__restrict__ flags,
+                                                                    const float *__restrict__ wf32, Geom geom)
 {
     using Cfg = ScanCfg<C, KH, KW, NTILE>;
     constexpr int NQ = Cfg::NQ, NT = Cfg::NT, NS = Cfg::NS, R = Cfg::R, RBB = Cfg::RBB, SLOTB = Cfg::SLOTB,
@@ -175,6 +177,7 @@ __global__ __launch_bounds__(64 * (C / 16) * NTILE) void k_scan_mfma(const float
 #pragma unroll
     for (int k = 0; k < RZ; ++k) zoff[k] = ((RZ - k) % RZ) * Cfg::ZSLOTB;
     int nst[3] = {0, 0, 0}; // store instructions this wave issued in the previous three steps
+    bool ovf = false;       // an r of this lane left the fp16 range (or is not a number)
 
     __syncthreads();
 
@@ -385,6 +388,7 @@ __global__ __launch_bounds__(64 * (C / 16) * NTILE) void k_scan_mfma(const float
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float rv = xv[r] + ahi[r] + amid[r] * LO_INV;
+                ovf |= (hval && w >= 0 && w < W) && !(fabsf(rv) < 6.0e4f);
                 const _Float16 h16 = (_Float16)rv;
                 hi[r] = h16;
                 lo[r] = (_Float16)((rv - (float)h16) * LO_SCALE);
@@ -425,6 +429,18 @@ __global__ __launch_bounds__(64 * (C / 16) * NTILE) void k_scan_mfma(const float
         else
             step(std::false_type{}, d);
     }
+    // Split fp16 cannot hold |r| >= 65504 (a badly conditioned operator grows r along the sweep): such an
+    // image is redone here, by the same workgroup, in exact fp32 from the fp32 copy of the same folded
+    // weights (general scan body, right-fold form).  Rare, slow, but never a silent Inf/NaN where the exact
+    // solver is finite.  flags[] records it for the caller (diagnostics only).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no LDS-DMA may still be landing in the LDS reused below
+    if (__syncthreads_or(ovf ? 1 : 0)) {
+        if (tid == 0) {
+            flags[b] = 1;
+            flags[gridDim.x] = 1;
+        }
+        scan_general_body<Cfg::THREADS>(xin, wf32, zout, geom, rh, rw, 1, (float *)lds, b, tid);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -451,8 +467,14 @@ __device__ __forceinline__ size_t w_index2(int co, int ci, int dh, int dw, int C
 
 template <int C>
 __global__ __launch_bounds__(256) void k_foldpack(const float *__restrict__ w, _Float16 *__restrict__ apack, Geom g,
-                                                  int transposed)
+                                                  int transposed, int mode, int *__restrict__ flags,
+                                                  float *__restrict__ wf32)
 {
+    // flags[0..B-1]: per-image overflow flags of the MFMA scan, flags[B]: any.  Mode 0 (always runs, ahead
+    // of the scan on the stream) clears them; mode 1 (fp32 left fold for the fallback) runs only if set.
+    if (mode == 1 && flags[g.B] == 0) return;
+    if (mode == 0 && blockIdx.x == 0)
+        for (int i = threadIdx.x; i <= g.B; i += 256) flags[i] = 0;
     constexpr int NBK = C / 16, XP = C + 1; // XP: fp64 row pitch (conflict-free row- and column-wise)
     __shared__ float sL[C * C];
     __shared__ double sX[C * XP];
@@ -539,6 +561,28 @@ __global__ __launch_bounds__(256) void k_foldpack(const float *__restrict__ w, _
         }
     }
 
+    if (mode == 1) {
+        // fp32 left fold for the general scan (prep.hip k_fold layout): wf[t][kc][c], t = dh*KW+dw,
+        //   t = 0 : L^-1 (transposed: L^-T);   t > 0 : L^-1 W_t (transposed: L^-T W_t^T)
+        // slot s of this grid maps to t = (s + 1) mod NT so that the NT slots cover t = 0..NT-1
+        const int t = (s + 1) % NT, dh = t / g.KW, dw = t % g.KW;
+        for (int idx = tid; idx < 16 * C; idx += 256) {
+            const int cl = idx / C, kc = idx % C, c = 16 * rgrp + cl;
+            double acc = 0.0;
+            if (t == 0) {
+                acc = transposed ? sX[kc * XP + c] : sX[c * XP + kc];
+            } else if (!transposed) {
+                for (int m = 0; m <= c; ++m)
+                    acc += sX[c * XP + m] * (double)w[w_index2(m, kc, dh, dw, C, g.KH, g.KW, g.flipH, g.flipW)];
+            } else {
+                for (int m = c; m < C; ++m)
+                    acc += sX[m * XP + c] * (double)w[w_index2(kc, m, dh, dw, C, g.KH, g.KW, g.flipH, g.flipW)];
+            }
+            wf32[((size_t)t * C + kc) * C + c] = (float)acc;
+        }
+        return;
+    }
+
     // ---- this workgroup's 16 rows of the slot: product, split, pack ------------------------------------
     for (int idx = tid; idx < 16 * C; idx += 256) {
         const int cl = idx / C, kc = idx % C, c = 16 * rgrp + cl;
@@ -561,6 +605,7 @@ __global__ __launch_bounds__(256) void k_foldpack(const float *__restrict__ w, _
             acc = -((a0 + a1) + (a2 + a3));
         }
         const float v = (float)acc;
+        if (wf32) wf32[((size_t)s * C + kc) * C + c] = v; // fp32 copy [slot][kc][c] for the fp32 fallback scan
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)((v - (float)hi) * LO_SCALE);
         const int q = kc / 32, gk = (kc % 32) / 8, j = kc % 8;
@@ -581,13 +626,17 @@ bool scan_mfma_supported(const Geom &g, const void *x, const void *z)
     return true;
 }
 
-int launch_foldpack_mfma(const float *w, void *apack, const Geom &g, int transposed, hipStream_t s)
+int launch_foldpack_mfma(const float *w, void *out, float *wf32, const Geom &g, int transposed, int mode, int *flags,
+                         hipStream_t s)
 {
     const int blocks = g.KH * g.KW * (g.C / 16);
+    if (mode == 1) wf32 = (float *)out;
     if (g.C == 64)
-        hipLaunchKernelGGL(k_foldpack<64>, dim3(blocks), dim3(256), 0, s, w, (_Float16 *)apack, g, transposed);
+        hipLaunchKernelGGL(k_foldpack<64>, dim3(blocks), dim3(256), 0, s, w, (_Float16 *)out, g, transposed, mode, flags,
+                           wf32);
     else if (g.C == 32)
-        hipLaunchKernelGGL(k_foldpack<32>, dim3(blocks), dim3(256), 0, s, w, (_Float16 *)apack, g, transposed);
+        hipLaunchKernelGGL(k_foldpack<32>, dim3(blocks), dim3(256), 0, s, w, (_Float16 *)out, g, transposed, mode, flags,
+                           wf32);
     else
         IFL_FAIL(IFL_EUNSUPPORTED, "launch_foldpack_mfma: C=%d", g.C);
     IFL_HIP(hipGetLastError());
@@ -595,7 +644,8 @@ int launch_foldpack_mfma(const float *w, void *apack, const Geom &g, int transpo
 }
 
 template <int C, int KH, int KW, int NTILE>
-static int launch_one(const float *x, float *z, const void *apack, const Geom &g, int rh, int rw, hipStream_t s)
+static int launch_one(const float *x, float *z, const void *apack, const Geom &g, int rh, int rw, int *flags,
+                      const float *wf32, hipStream_t s)
 {
     using Cfg = ScanCfg<C, KH, KW, NTILE>;
     static_assert(Cfg::LDSB <= 160 * 1024, "ring + x staging must fit the CU's LDS");
@@ -605,17 +655,20 @@ static int launch_one(const float *x, float *z, const void *apack, const Geom &g
                                     Cfg::LDSB));
         attr_done = true;
     }
+    if (scan_general_lds_bytes(g) > (size_t)Cfg::LDSB)
+        IFL_FAIL(IFL_EUNSUPPORTED, "launch_scan_mfma: fp32 fallback does not fit the kernel's LDS");
     hipLaunchKernelGGL((k_scan_mfma<C, KH, KW, NTILE>), dim3(g.B), dim3(Cfg::THREADS), Cfg::LDSB, s, x, z,
-                       (const half8 *)apack, g.H, g.W, rh, rw);
+                       (const half8 *)apack, g.H, g.W, rh, rw, flags, wf32, g);
     IFL_HIP(hipGetLastError());
     return IFL_OK;
 }
 
-int launch_scan_mfma(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, hipStream_t s)
+int launch_scan_mfma(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, int *flags,
+                     const float *wf32, hipStream_t s)
 {
     const int nt = g.H <= 16 ? 1 : 2;
 #define IFL_CASE(CC, KK, NN) \
-    if (g.C == CC && g.KH == KK && g.KW == KK && nt == NN) return launch_one<CC, KK, KK, NN>(x, z, apack, g, rh, rw, s);
+    if (g.C == CC && g.KH == KK && g.KW == KK && nt == NN) return launch_one<CC, KK, KK, NN>(x, z, apack, g, rh, rw, flags, wf32, s);
     IFL_CASE(64, 3, 1)
     IFL_CASE(64, 3, 2)
     IFL_CASE(32, 3, 1)

@@ -15,7 +15,7 @@ class NegativeGaussianLoss(nn.Module):
         self.dim = 1
         for s in self.size:
             self.dim *= int(s)
-        self._device_probe = nn.Parameter(torch.zeros(1), requires_grad=False)
+        self.register_buffer("_device_probe", torch.zeros(1), persistent=False)
 
     def forward(self, input, context=None):
         return -self.log_prob(input, context).sum(-1)

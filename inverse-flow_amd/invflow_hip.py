@@ -58,7 +58,7 @@ def lib():
     return _lib
 
 
-PROF_TAGS = {"scan": 0, "wgrad": 1, "conv": 2, "fold": 3}
+PROF_TAGS = {"scan": 0, "wgrad": 1, "conv": 2, "fold": 3, "fallback": 4}
 
 
 def profile_enable(on=True):

@@ -1,0 +1,75 @@
+"""CPU: the batch-sharded data-parallel path (one process per rank, gloo, world size 2): shard
+bounds, flat gradient bucket, all-reduce mean -- the N>1 logic bench.py and a training loop use."""
+import os
+import subprocess
+import sys
+
+import torch
+
+from conftest import PKG, ROOT
+
+import data_parallel as dp
+
+
+def test_shard_bounds_cover_batch():
+    for n in (0, 1, 7, 128, 130):
+        for world in (1, 2, 3, 8):
+            spans = [dp.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    x = torch.arange(10).view(10, 1)
+    assert torch.equal(dp.shard_batch(x, 1, 3), x[4:7])
+
+
+def test_grad_bucket_views():
+    lin = torch.nn.Linear(3, 2)
+    b = dp.GradBucket(lin.parameters())
+    assert b.flat.numel() == 8 and lin.weight.grad.data_ptr() == b.flat.data_ptr()
+    lin(torch.ones(1, 3)).sum().backward()
+    assert float(b.flat.abs().sum()) > 0
+    b.zero()
+    assert float(lin.weight.grad.abs().sum()) == 0.0
+    assert b.allreduce_mean() is None  # single process: no-op
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+import data_parallel as dp
+rank, local, world = dp.init("gloo")
+assert world == 2 and dist.get_world_size() == 2
+torch.manual_seed(0)
+model = torch.nn.Conv2d(4, 4, 3, padding=1, bias=False)
+dp.broadcast_parameters(model)
+bucket = dp.GradBucket(model.parameters())
+x = torch.randn(8, 4, 6, 6)             # same full batch on both ranks (same seed)
+ref = torch.nn.Conv2d(4, 4, 3, padding=1, bias=False)
+ref.load_state_dict(model.state_dict())
+ref(x).pow(2).mean().backward()          # single-process gradient of the mean loss
+xs = dp.shard_batch(x)                   # this rank's shard
+assert xs.shape[0] == 4
+bucket.zero()
+model(xs).pow(2).mean().backward()       # per-rank mean
+w = bucket.allreduce_mean(async_op=True)
+w.wait()
+assert torch.allclose(model.weight.grad, ref.weight.grad, atol=1e-6), (model.weight.grad - ref.weight.grad).abs().max()
+t = torch.full((3,), float(rank + 1))
+dp.allreduce_mean_(t)
+assert torch.allclose(t, torch.full((3,), 1.5))
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_two_rank_gloo_allreduce(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % (PKG, ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29531", str(script)],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert r.stdout.count("ok") == 2

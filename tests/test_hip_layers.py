@@ -1,0 +1,182 @@
+"""GPU: the `inf` operator surface on top of the HIP library -- layers, autograd, FlowSequential,
+the inv_conv_with_bp drop-in module, SelfNormConv -- against the oracle / golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_files, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def H():
+    assert torch.cuda.is_available()
+    import invflow_hip
+    invflow_hip.lib()
+    return invflow_hip
+
+
+def host(t):
+    return t.detach().cpu().double().numpy()
+
+
+def check_inverse(module, data_dim):
+    """tests/inf/test_layers.py:19-36 (check_inverse): forward then reverse, atol 1e-3."""
+    module.reset_parameters()
+    module.to("cuda")
+    x = torch.randn(data_dim).cuda()
+    fwd, logdet = module(x)
+    rev = module.reverse(fwd)
+    np.testing.assert_allclose(x.cpu().numpy(), rev.detach().cpu().view(data_dim).numpy(), atol=1e-3)
+    return logdet
+
+
+def test_reference_test_inv_conv(H):
+    """tests/inf/test_layers.py:182-190 (test_inv_conv): (1,4,5,5), 3x3, no_pad and with_pad TL."""
+    from inf.layers.inv_conv import inv_flow_no_pad, inv_flow_with_pad
+    torch.manual_seed(0)
+    size = (1, 4, 5, 5)
+    assert check_inverse(inv_flow_no_pad(4, 4, (3, 3)), size) == 0.0
+    assert check_inverse(inv_flow_with_pad(4, 4, (3, 3), order="TL"), size) == 0.0
+    check_inverse(inv_flow_with_pad(4, 4, (2, 2), order="TL"), size)  # test_layers.py:152
+    for order in ("TR", "BL", "BR"):
+        check_inverse(inv_flow_with_pad(4, 4, (3, 3), order=order), size)
+    for C, hw in ((64, 32), (32, 16)):  # MFMA path
+        for order in ("TL", "TR", "BL", "BR"):
+            check_inverse(inv_flow_with_pad(C, C, (3, 3), order=order), (3, C, hw, hw))
+
+
+@pytest.mark.parametrize("order", ["TL", "TR", "BL", "BR"])
+@pytest.mark.parametrize("shape", [(2, 6, 7, 5, 3), (3, 64, 32, 32, 3), (2, 32, 12, 16, 2)])
+def test_layer_autograd_matches_oracle(H, oracle, order, shape):
+    from inf.layers.inv_conv import inv_flow_with_pad
+    B, C, Hh, Ww, K = shape
+    torch.manual_seed(hash((order, shape)) % 1000)
+    layer = inv_flow_with_pad(C, C, (K, K), order=order).cuda()
+    with torch.no_grad():
+        layer.weight_fwd.add_(0.02 * torch.randn_like(layer.weight_fwd))
+    x = torch.randn(B, C, Hh, Ww, device="cuda", requires_grad=True)
+    g = torch.randn(B, C, Hh, Ww, device="cuda")
+    z, ldj = layer(x)
+    assert ldj == 0.0
+    (z * g).sum().backward()
+    w64, x64, g64 = host(layer.weight_fwd), host(x), host(g)
+    z_o = oracle.inverse(x64, w64, 0, order, nthreads=8)
+    u_o = oracle.dy(g64, w64, 0, order, nthreads=8)
+    dw_o = oracle.dw(z_o, u_o, (K, K), 0, order, nthreads=8)
+    assert rel_err(host(z), z_o) < TOL
+    assert rel_err(host(x.grad), u_o) < TOL
+    assert rel_err(host(layer.weight_fwd.grad), dw_o) < TOL
+    # the gradient already carries the mask of reset_gradients (inv_conv.py:223-230)
+    before = layer.weight_fwd.grad.clone()
+    layer.reset_gradients()
+    assert torch.equal(before, layer.weight_fwd.grad)
+    # the MFMA kernels and the general kernels are two statements of the same op
+    if C % 32 == 0:
+        z2 = H.inverse(x.detach(), layer.weight_fwd.detach(), order, H.FLAG_NO_MFMA)
+        dx2, dw2, _ = H.backward(g, z2, layer.weight_fwd.detach(), order, H.FLAG_NO_MFMA)
+        assert rel_err(host(z2), z_o) < TOL and rel_err(host(dx2), u_o) < TOL and rel_err(host(dw2), dw_o) < TOL
+
+
+def test_inv_flow_unit_and_sequential(H):
+    from inf.layers.flowsequential import FlowSequential
+    from inf.layers.inv_conv import inv_flow_no_pad
+    from inf.layers.inv_flow import Inv_FlowUnit
+    from inf.train.losses import NegativeGaussianLoss
+    torch.manual_seed(3)
+    C, S = 8, 8
+    unit = Inv_FlowUnit(C, C, (3, 3)).cuda()
+    x = torch.randn(5, C, S, S, device="cuda")
+    y, ld = unit(x)
+    assert ld == 0.0
+    np.testing.assert_allclose(host(unit.reverse(y)), host(x), atol=1e-3)
+    model = FlowSequential(NegativeGaussianLoss((C, S, S)), inv_flow_no_pad(C, C, (3, 3)), unit,
+                           inv_flow_no_pad(C, C, (2, 2))).cuda()
+    out, lp = model(x)
+    assert torch.allclose(lp, model.base_distribution.log_prob(out))  # every layer has log-det 0, counted once
+    assert rel_err(host(model.reconstruct(x)), host(x)) < 1e-3  # six inverse + six forward layers in fp32
+    samples, _ = model.sample(4)
+    assert samples.shape == (4, C, S, S) and torch.isfinite(samples).all()
+    loss = -lp.mean()
+    loss.backward()
+    ps = list(model.parameters())
+    assert len(ps) == 6 and all(p.grad is not None and torch.isfinite(p.grad).all() for p in ps)
+
+
+def test_drop_in_extension_module(H, oracle):
+    """The four functions of the reference pybind module (inv_conv_with_bp_general.cpp:115-120) with the
+    reference calling convention: caller-allocated outputs, list return, scratch M ignored."""
+    import inv_conv_with_bp as ext
+    rng = np.random.default_rng(11)
+    B, C, S, K = 2, 8, 6, 3
+    x = torch.tensor(rng.standard_normal((B, C, S, S)), dtype=torch.float32).cuda()
+    g = torch.tensor(rng.standard_normal((B, C, S, S)), dtype=torch.float32).cuda()
+    w = torch.tensor(rng.standard_normal((C, C, K, K)) * 0.05, dtype=torch.float32).cuda()
+    out = x * 0.0  # inv_conv.py:48
+    z = ext.inverse(x, w, out)
+    assert isinstance(z, list) and z[0] is out
+    z_o = oracle.inverse(host(x), host(w))
+    assert rel_err(host(out), z_o) < TOL
+    rev = ext.forward(out, w, torch.zeros_like(x))
+    assert rel_err(host(rev[0]), host(x)) < TOL
+    M_dy = torch.zeros_like(x)
+    M_dk = torch.zeros((B, C, K, K, S, S), device="cuda")  # inv_conv.py:70
+    dyv = ext.dy(g, w, M_dy, torch.zeros_like(x))
+    u_o = oracle.dy(host(g), host(w))
+    assert rel_err(host(dyv[0]), u_o) < TOL
+    dk = ext.dw(x, w, g, M_dk, torch.zeros_like(w))
+    assert rel_err(host(dk[0]), oracle.dw(z_o, u_o, (K, K))) < TOL
+    with pytest.raises(RuntimeError, match="must be contiguous"):
+        ext.inverse(x.transpose(2, 3), w, out)
+
+
+@pytest.mark.parametrize("path", golden_files("selfnorm_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_selfnorm_matches_golden(H, path):
+    from inf.layers.selfnorm import selfnorm_conv_2d
+    g = load_golden(path)
+    p = (g["pad"], g["pad"])
+    t = lambda a: torch.tensor(a, dtype=torch.float32).cuda()  # noqa: E731
+    x = t(g["x"]).requires_grad_(True)
+    W = t(g["w"]).requires_grad_(True)
+    R = t(g["r"]).requires_grad_(True)
+    b = t(g["bias"]).requires_grad_(True) if "bias" in g else None
+    z = selfnorm_conv_2d(x, W, b, R, (1, 1), p)
+    assert rel_err(host(z), g["z"]) < TOL
+    z.backward(t(g["gz"]))
+    assert rel_err(host(x.grad), g["dx"]) < TOL
+    assert rel_err(host(W.grad), g["dw_fwd"]) < TOL
+    assert rel_err(host(R.grad), g["dw_inv"]) < TOL
+    if b is not None:
+        assert rel_err(host(b.grad), g["dbias"]) < TOL
+
+
+@pytest.mark.parametrize("sym", [False, True])
+def test_selfnorm_layer_recon_and_exact(H, sym):
+    from inf.layers.selfnorm import SelfNormConv, SelfNormFC
+    g = load_golden(golden_files("selfnorm_b3c4_8x8_k3_p1")[0])
+    t = lambda a: torch.tensor(a, dtype=torch.float32).cuda()  # noqa: E731
+    layer = SelfNormConv(4, 4, (3, 3), bias=False, padding=1, sym_recon_grad=sym).cuda()
+    with torch.no_grad():
+        layer.weight_fwd.copy_(t(g["w"]))
+        layer.weight_inv.copy_(t(g["r"]))
+    x = t(g["x"])
+    layer(x)
+    loss = layer.add_recon_grad()
+    tag = "sym" if sym else "asym"
+    assert abs(float(loss) - g["recon_loss_" + tag]) < 1e-4 * abs(g["recon_loss_" + tag])
+    assert rel_err(host(layer.weight_fwd.grad), g["recon_dw_" + tag]) < 1e-4
+    assert rel_err(host(layer.weight_inv.grad), g["recon_dr_" + tag]) < 1e-4
+    # exact mode (tests/inf/test_layers.py:39-46, 101-108): dense inverse round trip and slogdet
+    out, ld = layer(x, compute_expensive=True)
+    rev = layer.reverse(out, compute_expensive=True)
+    np.testing.assert_allclose(host(rev), host(x), atol=1e-3)
+    J = torch.autograd.functional.jacobian(lambda a: torch.nn.functional.conv2d(a[None], layer.weight_fwd.detach().cpu().double(), None, 1, 1)[0],
+                                           x[0].cpu().double())
+    ld_ref = torch.slogdet(J.reshape(256, 256))[1]
+    np.testing.assert_allclose(host(ld)[0], float(ld_ref), atol=1e-4)
+    fc = SelfNormFC(12, 12).cuda()
+    xf = torch.randn(5, 12, device="cuda")
+    of, ldf = fc(xf, compute_expensive=True)
+    np.testing.assert_allclose(host(fc.reverse(of, compute_expensive=True)), host(xf), atol=1e-3)

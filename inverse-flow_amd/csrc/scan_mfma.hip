@@ -208,7 +208,9 @@ __global__ __launch_bounds__(64 * (C / 16) * NTILE) void k_scan_mfma(const float
                                                  (void __attribute__((address_space(3))) *)dst, 16, 0, 0);
         }
 
-        floatx4 ahi = {0.f, 0.f, 0.f, 0.f}, amid = {0.f, 0.f, 0.f, 0.f};
+        // three accumulator chains (hi*hi, hi*lo', lo'*hi): back-to-back MFMAs into the same accumulator
+        // issue at ~28 cycles each from a single wave, three independent chains at ~19 (tools/mfma_rate_probe.hip)
+        floatx4 ahi = {0.f, 0.f, 0.f, 0.f}, amid = {0.f, 0.f, 0.f, 0.f}, amid2 = {0.f, 0.f, 0.f, 0.f};
 
         // (tap, k-step) units of a phase.  SEL 0: taps two or more diagonals back (no dependence on step
         // d-1), SEL 1: the two taps on diagonal d-1.
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(64 * (C / 16) * NTILE) void k_scan_mfma(const float
             const int t = unit_tap(sel, u), q = unit_q(sel, u);
             ahi = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], vh, ahi, 0, 0, 0);
             amid = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], vl, amid, 0, 0, 0);
-            amid = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][1], vh, amid, 0, 0, 0);
+            amid2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][1], vh, amid2, 0, 0, 0);
         };
 
         // ---- (B) old taps: a PF-deep register ring of fragments keeps the LDS latency (a few hundred
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(64 * (C / 16) * NTILE) void k_scan_mfma(const float
             half4 hi, lo;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float rv = xv[r] + ahi[r] + amid[r] * LO_INV;
+                const float rv = xv[r] + ahi[r] + (amid[r] + amid2[r]) * LO_INV;
                 ovf |= (hval && w >= 0 && w < W) && !(fabsf(rv) < 6.0e4f);
                 const _Float16 h16 = (_Float16)rv;
                 hi[r] = h16;

@@ -230,14 +230,12 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
         half8 As[NKS][2];                                                                                          \
         _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks) _Pragma("unroll") for (int hl = 0; hl < 2; ++hl)        \
             As[ks][hl] = shift_frag<J>(Au[ks][hl], head[ks][hl]);                                                  \
-        _Pragma("unroll") for (int i = 0; i < KH; ++i) _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks)          \
-        {                                                                                                          \
-            floatx16 c_ = acc[i * KW + J];                                                                         \
-            c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(As[ks][0], Bz[i][ks][0], c_, 0, 0, 0);                     \
-            c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(As[ks][0], Bz[i][ks][1], c_, 0, 0, 0);                     \
-            c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(As[ks][1], Bz[i][ks][0], c_, 0, 0, 0);                     \
-            acc[i * KW + J] = c_;                                                                                  \
-        }                                                                                                          \
+        /* consecutive MFMAs go to different accumulators (rows i of the tap column J): back-to-back MFMAs    */ \
+        /* into one accumulator issue ~1.5x slower from a single wave (tools/mfma_rate_probe.hip)             */ \
+        _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks) _Pragma("unroll") for (int pr = 0; pr < 3; ++pr)        \
+            _Pragma("unroll") for (int i = 0; i < KH; ++i)                                                          \
+                acc[i * KW + J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(As[ks][pr == 2 ? 1 : 0],                   \
+                                                                           Bz[i][ks][pr == 1 ? 1 : 0], acc[i * KW + J], 0, 0, 0); \
     }
             IFL_WG_TAPS(0)
             if constexpr (KW > 1) IFL_WG_TAPS(1)

@@ -118,9 +118,11 @@ def main():
     dx = torch.empty_like(x)
     dw = torch.empty_like(w)
 
+    carry = H.new_carry(w)  # forward -> backward side channel of a step (what the autograd ctx carries)
+
     def step():
-        H.inverse(x, w, "TL", args.flags, out=z)
-        H.backward(g, z, w, "TL", args.flags, dx_out=dx, dw_out=dw)
+        H.inverse(x, w, "TL", args.flags, out=z, carry=carry)
+        H.backward(g, z, w, "TL", args.flags, dx_out=dx, dw_out=dw, carry=carry)
         if world > 1:
             dp.allreduce_mean_(dw)
 

@@ -77,7 +77,16 @@ size_t ifl_workspace_bytes(int op, int B, int C, int H, int W, int KH, int KW, u
  * called from inv_conv_.forward (inf/layers/inv_conv.py:46-60).  Exact semantics = solve_mc.py:88-114.
  */
 int ifl_inverse_f32(const float *x, const float *w, float *z, int B, int C, int H, int W, int KH, int KW,
-                    int order, unsigned flags, void *ws, size_t ws_bytes, ifl_stream_t stream);
+                    int order, unsigned flags, void *ws, size_t ws_bytes, void *carry, ifl_stream_t stream);
+
+/*
+ * Optional forward -> backward side channel (the analogue of ctx.save_for_backward, inf/layers/inv_conv.py:56):
+ * a caller-owned device buffer of ifl_carry_bytes() that ifl_inverse_f32 fills with the folded weights of
+ * the adjoint operator and max|z|, and that ifl_backward_f32 of the SAME step (same w, shape, order, flags)
+ * reads instead of folding again and scanning z / dx for their maxima.  Pass NULL to either call to
+ * disable it; results are identical either way.
+ */
+size_t ifl_carry_bytes(int C, int KH, int KW);
 
 /*
  * xhat = A z (+ log|det A| per image) -- the layer's reverse / sampling / reconstruction pass.
@@ -105,7 +114,7 @@ int ifl_forward_f32(const float *z, const float *w, float *xhat, float *logdet, 
  */
 int ifl_backward_f32(const float *g, const float *z, const float *x, const float *w, float *dx, float *dw,
                      float recon_weight, float *recon_loss, int B, int C, int H, int W, int KH, int KW,
-                     int order, unsigned flags, void *ws, size_t ws_bytes, ifl_stream_t stream);
+                     int order, unsigned flags, void *ws, size_t ws_bytes, void *carry, ifl_stream_t stream);
 
 /*
  * Weight gradient from a precomputed dx:  dw = -(sum dx (x) shifted z) * mask.

@@ -90,26 +90,77 @@ static size_t fold_bytes(int B, int C, int KH, int KW)
            align_up(((size_t)B + 1) * sizeof(int), 256) + 1024;
 }
 
+// Forward -> backward side channel ("carry", caller-owned, ifl_carry_bytes): the folded + packed weights of
+// the adjoint, produced by the forward call's single fold launch, and two words collecting max|z| / max|dx|
+// from the scans (the weight-gradient kernel's power-of-two prescale), so that the backward needs neither
+// a fold launch nor a pass over z and dx.
+struct CarryView {
+    unsigned *zmax, *dxmax;
+    void *adj_pack;
+    float *adj_wf32;
+};
+static size_t carry_bytes(int C, int KH, int KW)
+{
+    return 256 + 2 * align_up((size_t)KH * KW * C * C * sizeof(float), 256);
+}
+static CarryView carry_view(void *carry, int C, int KH, int KW)
+{
+    char *p = (char *)carry;
+    CarryView v;
+    v.zmax = (unsigned *)p;
+    v.dxmax = (unsigned *)(p + 64);
+    v.adj_pack = p + 256;
+    v.adj_wf32 = (float *)(p + 256 + align_up((size_t)KH * KW * C * C * sizeof(float), 256));
+    return v;
+}
+// the carry is used iff the *shape* can take the MFMA scan: both calls evaluate this on the host
+static bool carry_usable(const Geom &g, unsigned flags)
+{
+    static float dummy_aligned __attribute__((aligned(16)));
+    return !(flags & (IFL_FLAG_NO_MFMA | IFL_FLAG_EXACT_F32)) && scan_mfma_supported(g, &dummy_aligned, &dummy_aligned);
+}
+
 // fold + scan (shared by inverse and dx): z = scan(x) for the operator or its adjoint.
+//   carry_out (forward): also fold the adjoint into the carry and collect max|z| there.
+//   carry_in (backward, transposed): take the packed adjoint from the carry, collect max|dx| there.
+// *amax_valid tells the caller whether the scan wrote max|output| into the carry word.
 static int run_scan(const float *x, const float *w, float *z, const Geom &g, int transposed, unsigned flags,
-                    Carver &cv, hipStream_t s)
+                    Carver &cv, void *carry_out, void *carry_in, bool *amax_valid, hipStream_t s)
 {
     double *linv = cv.take<double>((size_t)g.C * g.C);
     float *wf = cv.take<float>((size_t)g.KH * g.KW * g.C * g.C); // folded taps (fp32) or packed fp16 hi/lo fragments
-    float *wf2 = cv.take<float>((size_t)g.KH * g.KW * g.C * g.C); // fp32 left fold of the overflow fallback
-    int *ovf = cv.take<int>((size_t)g.B + 1);                    // per-image + any overflow flags of the MFMA scan
+    float *wf2 = cv.take<float>((size_t)g.KH * g.KW * g.C * g.C); // fp32 copy of the folded taps (in-kernel fp32 redo)
+    int *ovf = cv.take<int>((size_t)g.B + 1);                    // per-image overflow flags of the MFMA scan
     if (!cv.ok()) IFL_FAIL(IFL_EWORKSPACE, "workspace too small: need %zu bytes, have %zu", cv.off, cv.cap);
     int rc;
+    if (amax_valid) *amax_valid = false;
     const int rh = g.flipH ^ (transposed ? 1 : 0), rw = g.flipW ^ (transposed ? 1 : 0);
-    const bool mfma = !(flags & (IFL_FLAG_NO_MFMA | IFL_FLAG_EXACT_F32)) && scan_mfma_supported(g, x, z);
+    const bool usable = carry_usable(g, flags);
+    const bool mfma = usable && scan_mfma_supported(g, x, z);
+    CarryView co{}, ci{};
+    if (carry_out && usable) co = carry_view(carry_out, g.C, g.KH, g.KW);
+    if (carry_in && usable) ci = carry_view(carry_in, g.C, g.KH, g.KW);
+    if (co.zmax) {
+        // one launch folds both directions (needed even if this call's pointers force the general scan)
+        ProfScope ps(IFL_PROF_FOLD, s);
+        if ((rc = launch_foldpack_mfma(w, wf, wf2, co.adj_pack, co.adj_wf32, g, transposed, 2, co.zmax, co.dxmax, s)))
+            return rc;
+    }
     if (mfma) {
-        {
+        const void *pack = wf;
+        const float *pack32 = wf2;
+        if (ci.zmax) {
+            pack = ci.adj_pack;
+            pack32 = ci.adj_wf32;
+        } else if (!co.zmax) {
             ProfScope ps(IFL_PROF_FOLD, s);
-            if ((rc = launch_foldpack_mfma(w, wf, wf2, g, transposed, 0, ovf, s))) return rc;
+            if ((rc = launch_foldpack_mfma(w, wf, wf2, nullptr, nullptr, g, transposed, 1, nullptr, nullptr, s))) return rc;
         }
-        // (an image whose r leaves the fp16 range is redone in exact fp32 inside the same launch, from wf2)
+        unsigned *amax = co.zmax ? co.zmax : (ci.zmax ? ci.dxmax : nullptr);
+        if (amax_valid) *amax_valid = amax != nullptr;
+        // (an image whose r leaves the fp16 range is redone in exact fp32 inside the same launch)
         ProfScope ps(IFL_PROF_SCAN, s);
-        return launch_scan_mfma(x, wf, z, g, rh, rw, ovf, wf2, s);
+        return launch_scan_mfma(x, pack, z, g, rh, rw, ovf, pack32, amax, s);
     }
     {
         ProfScope ps(IFL_PROF_FOLD, s);
@@ -189,8 +240,14 @@ size_t ifl_workspace_bytes(int op, int B, int C, int H, int W, int KH, int KW, u
     }
 }
 
+size_t ifl_carry_bytes(int C, int KH, int KW)
+{
+    if (C < 1 || KH < 1 || KW < 1) return 0;
+    return carry_bytes(C, KH, KW);
+}
+
 int ifl_inverse_f32(const float *x, const float *w, float *z, int B, int C, int H, int W, int KH, int KW, int order,
-                    unsigned flags, void *ws, size_t ws_bytes, ifl_stream_t stream)
+                    unsigned flags, void *ws, size_t ws_bytes, void *carry, ifl_stream_t stream)
 {
     clear_error();
     int rc = check_shape("ifl_inverse_f32", B, C, H, W, KH, KW, order);
@@ -199,7 +256,15 @@ int ifl_inverse_f32(const float *x, const float *w, float *z, int B, int C, int 
     if (!x || !w || !z) IFL_FAIL(IFL_EINVAL, "ifl_inverse_f32: null tensor pointer");
     Geom g = make_geom(B, C, H, W, KH, KW, order, flags);
     Carver cv(ws, ws_bytes);
-    return run_scan(x, w, z, g, 0, flags, cv, (hipStream_t)stream);
+    bool amax_ok = false;
+    rc = run_scan(x, w, z, g, 0, flags, cv, carry, nullptr, &amax_ok, (hipStream_t)stream);
+    if (rc) return rc;
+    if (carry && carry_usable(g, flags) && !amax_ok) {
+        // the general scan ran (unaligned pointers): collect max|z| with a streaming pass (rare path)
+        const CarryView cvw = carry_view(carry, C, KH, KW);
+        if ((rc = launch_absmax(z, (size_t)B * C * H * W, cvw.zmax, (hipStream_t)stream))) return rc;
+    }
+    return IFL_OK;
 }
 
 int ifl_forward_f32(const float *z, const float *w, float *xhat, float *logdet, int B, int C, int H, int W, int KH,
@@ -226,14 +291,10 @@ int ifl_forward_f32(const float *z, const float *w, float *xhat, float *logdet, 
     return IFL_OK;
 }
 
-int ifl_dw_f32(const float *z, const float *dx, float *dw, int B, int C, int H, int W, int KH, int KW, int order,
-               unsigned flags, void *ws, size_t ws_bytes, ifl_stream_t stream)
+static int dw_impl(const float *z, const float *dx, float *dw, int B, int C, int H, int W, int KH, int KW, int order,
+                   unsigned flags, void *ws, size_t ws_bytes, const unsigned *amax_dx, const unsigned *amax_z,
+                   hipStream_t s)
 {
-    clear_error();
-    int rc = check_shape("ifl_dw_f32", B, C, H, W, KH, KW, order);
-    if (rc) return rc;
-    if (!dw || (B > 0 && (!z || !dx))) IFL_FAIL(IFL_EINVAL, "ifl_dw_f32: null tensor pointer");
-    hipStream_t s = (hipStream_t)stream;
     Geom g = make_geom(B, C, H, W, KH, KW, order, flags);
     if (B == 0) {
         IFL_HIP(hipMemsetAsync(dw, 0, (size_t)C * C * KH * KW * sizeof(float), s));
@@ -247,16 +308,26 @@ int ifl_dw_f32(const float *z, const float *dx, float *dw, int B, int C, int H, 
         void *wws = cv.take<char>(wgrad_mfma_workspace_bytes(B, C, H, KH, KW));
         if (cv.ok())
             return launch_wgrad_mfma(dx, z, dw, wws, B, C, H, W, KH, KW, pt, pl, -1.0f, g.general_diag ? 2 : 1, dkh,
-                                     dkw, s);
+                                     dkw, amax_dx, amax_z, s);
         IFL_FAIL(IFL_EWORKSPACE, "ifl_dw_f32: workspace too small: need %zu bytes, have %zu", cv.off, cv.cap);
     }
     return launch_wgrad_direct(dx, z, dw, B, C, C, H, W, H, W, KH, KW, pt, pl, -1.0f, g.general_diag ? 2 : 1, dkh, dkw,
                                s);
 }
 
+int ifl_dw_f32(const float *z, const float *dx, float *dw, int B, int C, int H, int W, int KH, int KW, int order,
+               unsigned flags, void *ws, size_t ws_bytes, ifl_stream_t stream)
+{
+    clear_error();
+    int rc = check_shape("ifl_dw_f32", B, C, H, W, KH, KW, order);
+    if (rc) return rc;
+    if (!dw || (B > 0 && (!z || !dx))) IFL_FAIL(IFL_EINVAL, "ifl_dw_f32: null tensor pointer");
+    return dw_impl(z, dx, dw, B, C, H, W, KH, KW, order, flags, ws, ws_bytes, nullptr, nullptr, (hipStream_t)stream);
+}
+
 int ifl_backward_f32(const float *gout, const float *z, const float *x, const float *w, float *dx, float *dw,
                      float recon_weight, float *recon_loss, int B, int C, int H, int W, int KH, int KW, int order,
-                     unsigned flags, void *ws, size_t ws_bytes, ifl_stream_t stream)
+                     unsigned flags, void *ws, size_t ws_bytes, void *carry, ifl_stream_t stream)
 {
     clear_error();
     int rc = check_shape("ifl_backward_f32", B, C, H, W, KH, KW, order);
@@ -275,7 +346,8 @@ int ifl_backward_f32(const float *gout, const float *z, const float *x, const fl
     const bool recon = dw && x && recon_weight != 0.0f;
     Carver cv(ws, ws_bytes);
     float *u = dx ? dx : cv.take<float>(n);
-    if ((rc = run_scan(gout, w, u, g, 1, flags, cv, s))) return rc;
+    bool dxmax_ok = false;
+    if ((rc = run_scan(gout, w, u, g, 1, flags, cv, nullptr, carry, &dxmax_ok, s))) return rc;
     if (!dw) return IFL_OK;
     const float *gsrc = u;
     if (recon) {
@@ -300,7 +372,14 @@ int ifl_backward_f32(const float *gout, const float *z, const float *x, const fl
         cv.off = align_up(cv.off, 256);
         char *rest = cv.base ? cv.base + cv.off : nullptr;
         const size_t rest_bytes = cv.cap > cv.off ? cv.cap - cv.off : 0;
-        return ifl_dw_f32(z, gsrc, dw, B, C, H, W, KH, KW, order, flags, rest, rest_bytes, stream);
+        // max|dx| and max|z| collected by the two scans make the weight gradient's own pass over them unnecessary
+        const unsigned *amax_dx = nullptr, *amax_z = nullptr;
+        if (carry && dxmax_ok && !recon && carry_usable(g, flags)) {
+            const CarryView cvw = carry_view(carry, C, KH, KW);
+            amax_dx = cvw.dxmax;
+            amax_z = cvw.zmax;
+        }
+        return dw_impl(z, gsrc, dw, B, C, H, W, KH, KW, order, flags, rest, rest_bytes, amax_dx, amax_z, s);
     }
 }
 

@@ -68,16 +68,23 @@ bool scan_mfma_supported(const Geom &g, const void *x, const void *z);
 size_t scan_mfma_pack_bytes(const Geom &g);
 // mode 0: packed split-fp16 A fragments of the right fold (also zeroes the B overflow flags + the any-flag);
 // mode 1: fp32 left fold wf[t][kc][c] for the general scan, skipped unless *gate_any != 0 (overflow fallback)
-int launch_foldpack_mfma(const float *w, void *out, float *wf32, const Geom &g, int transposed, int mode, int *flags,
-                         hipStream_t s);
+// ndir = 1: one direction (`transposed`) -> out0/wf0.  ndir = 2: the operator -> out0/wf0 and its adjoint ->
+// out1/wf1 in one launch.  zero0/zero1: optional words cleared by the launch (absmax accumulators).
+int launch_foldpack_mfma(const float *w, void *out0, float *wf0, void *out1, float *wf1, const Geom &g, int transposed,
+                         int ndir, unsigned *zero0, unsigned *zero1, hipStream_t s);
+// amax: optional device word that receives max|z| (atomicMax of float bits; must be cleared beforehand)
 int launch_scan_mfma(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, int *flags,
-                     const float *wf32, hipStream_t s);
+                     const float *wf32, unsigned *amax, hipStream_t s);
 
 // ---- MFMA weight gradient (wgrad_mfma.hip): C in {32,64}, W in {16,32}, K in {2x2,3x3}, corner pads ----
 bool wgrad_mfma_supported(int B, int C, int H, int W, int KH, int KW, int pt, int pl, const void *gz, const void *x);
 size_t wgrad_mfma_workspace_bytes(int B, int C, int H, int KH, int KW);
+// *out = max|a| as float bits (out must not need clearing: the launch clears it first)
+int launch_absmax(const float *a, size_t n, unsigned *out, hipStream_t s);
+// amax_gz / amax_x: device words holding (an upper bound of) max|gz|, max|x| as float bits, or NULL to compute them
 int launch_wgrad_mfma(const float *gz, const float *x, float *dw, void *ws, int B, int C, int H, int W, int KH, int KW,
-                      int pt, int pl, float scale, int mask_mode, int mkh, int mkw, hipStream_t s);
+                      int pt, int pl, float scale, int mask_mode, int mkh, int mkw, const unsigned *amax_gz,
+                      const unsigned *amax_x, hipStream_t s);
 
 // ---- general (any C, any K) VALU kernels (scan_general.hip, conv_general.hip) ----------------
 size_t scan_general_lds_bytes(const Geom &g);

@@ -107,7 +107,8 @@ __global__ __launch_bounds__(64 * (C / 16) * NTILE) void k_scan_mfma(const float
                                                                     float *__restrict__ zout,
                                                                     const half8 *__restrict__ apack, int H, int W,
                                                                     int rh, int rw, int *__restrict__ flags,
-                                                                    const float *__restrict__ wf32, Geom geom)
+                                                                    const float *__restrict__ wf32, Geom geom,
+                                                                    unsigned *__restrict__ amax)
 {
     using Cfg = ScanCfg<C, KH, KW, NTILE>;
     constexpr int NQ = Cfg::NQ, NT = Cfg::NT, NS = Cfg::NS, R = Cfg::R, RBB = Cfg::RBB, SLOTB = Cfg::SLOTB,
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(64 * (C / 16) * NTILE) void k_scan_mfma(const float
     for (int k = 0; k < RZ; ++k) zoff[k] = ((RZ - k) % RZ) * Cfg::ZSLOTB;
     int nst[3] = {0, 0, 0}; // store instructions this wave issued in the previous three steps
     bool ovf = false;       // an r of this lane left the fp16 range (or is not a number)
+    float zmax = 0.f;       // max |z| this lane stored (handed to the weight-gradient kernel as its prescale)
 
     __syncthreads();
 
@@ -208,9 +210,9 @@ __global__ __launch_bounds__(64 * (C / 16) * NTILE) void k_scan_mfma(const float
                                                  (void __attribute__((address_space(3))) *)dst, 16, 0, 0);
         }
 
-        // three accumulator chains (hi*hi, hi*lo', lo'*hi): back-to-back MFMAs into the same accumulator
-        // issue at ~28 cycles each from a single wave, three independent chains at ~19 (tools/mfma_rate_probe.hip)
-        floatx4 ahi = {0.f, 0.f, 0.f, 0.f}, amid = {0.f, 0.f, 0.f, 0.f}, amid2 = {0.f, 0.f, 0.f, 0.f};
+        // two accumulator chains: hi*hi and the 2^-11-scaled cross terms hi*lo' + lo'*hi (a third chain for
+        // the second cross term measured slower in the full kernel although faster in isolation)
+        floatx4 ahi = {0.f, 0.f, 0.f, 0.f}, amid = {0.f, 0.f, 0.f, 0.f};
 
         // (tap, k-step) units of a phase.  SEL 0: taps two or more diagonals back (no dependence on step
         // d-1), SEL 1: the two taps on diagonal d-1.
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(64 * (C / 16) * NTILE) void k_scan_mfma(const float
             const int t = unit_tap(sel, u), q = unit_q(sel, u);
             ahi = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], vh, ahi, 0, 0, 0);
             amid = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], vl, amid, 0, 0, 0);
-            amid2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][1], vh, amid2, 0, 0, 0);
+            amid = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][1], vh, amid, 0, 0, 0);
         };
 
         // ---- (B) old taps: a PF-deep register ring of fragments keeps the LDS latency (a few hundred
@@ -381,7 +383,10 @@ __global__ __launch_bounds__(64 * (C / 16) * NTILE) void k_scan_mfma(const float
                 const int hs = rh ? H - 1 - hr : hr;
                 const int ws = rw ? W - 1 - w3 : w3 - 3;
                 char *dstp = zg + ((size_t)hs * W + ws) * sizeof(float); // wave-uniform
-                if (C == 64 || lane < C) *(floatx4 *)(dstp + voff) = sv[i];
+                if (C == 64 || lane < C) {
+                    *(floatx4 *)(dstp + voff) = sv[i];
+                    zmax = fmaxf(zmax, fmaxf(fmaxf(fabsf(sv[i][0]), fabsf(sv[i][1])), fmaxf(fabsf(sv[i][2]), fabsf(sv[i][3]))));
+                }
             }
 
         // ---- epilogue: r_d -> split fp16 -> ring; z_{d-1} -> z-ring ----------------------------------------
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(64 * (C / 16) * NTILE) void k_scan_mfma(const float
             half4 hi, lo;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float rv = xv[r] + ahi[r] + (amid[r] + amid2[r]) * LO_INV;
+                const float rv = xv[r] + ahi[r] + amid[r] * LO_INV;
                 ovf |= (hval && w >= 0 && w < W) && !(fabsf(rv) < 6.0e4f);
                 const _Float16 h16 = (_Float16)rv;
                 hi[r] = h16;
@@ -436,12 +441,20 @@ __global__ __launch_bounds__(64 * (C / 16) * NTILE) void k_scan_mfma(const float
     // weights (general scan body, right-fold form).  Rare, slow, but never a silent Inf/NaN where the exact
     // solver is finite.  flags[] records it for the caller (diagnostics only).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no LDS-DMA may still be landing in the LDS reused below
-    if (__syncthreads_or(ovf ? 1 : 0)) {
-        if (tid == 0) {
-            flags[b] = 1;
-            flags[gridDim.x] = 1;
-        }
+    const int redo = __syncthreads_or(ovf ? 1 : 0);
+    if (tid == 0) flags[b] = redo ? 1 : 0; // every workgroup owns its word: no clearing pass needed
+    if (redo) {
         scan_general_body<Cfg::THREADS>(xin, wf32, zout, geom, rh, rw, 1, (float *)lds, b, tid);
+        if (amax) { // the quads stored above are void: take the maximum of what the redo wrote
+            __syncthreads();
+            const float *zi = zout + (size_t)b * C * H * W;
+            zmax = 0.f;
+            for (int i = tid; i < C * H * W; i += Cfg::THREADS) zmax = fmaxf(zmax, fabsf(zi[i]));
+        }
+    }
+    if (amax) {
+        for (int o = 32; o > 0; o >>= 1) zmax = fmaxf(zmax, __shfl_down(zmax, o, 64));
+        if (lane == 0) atomicMax(amax, __float_as_uint(zmax)); // one atomic per wave; max is order-independent
     }
 }
 
@@ -468,15 +481,21 @@ __device__ __forceinline__ size_t w_index2(int co, int ci, int dh, int dw, int C
 }
 
 template <int C>
-__global__ __launch_bounds__(256) void k_foldpack(const float *__restrict__ w, _Float16 *__restrict__ apack, Geom g,
-                                                  int transposed, int mode, int *__restrict__ flags,
-                                                  float *__restrict__ wf32)
+__global__ __launch_bounds__(256) void k_foldpack(const float *__restrict__ w, _Float16 *__restrict__ apack0,
+                                                  float *__restrict__ wf0, _Float16 *__restrict__ apack1,
+                                                  float *__restrict__ wf1, Geom g, int transposed0,
+                                                  unsigned *__restrict__ zero0, unsigned *__restrict__ zero1)
 {
-    // flags[0..B-1]: per-image overflow flags of the MFMA scan, flags[B]: any.  Mode 0 (always runs, ahead
-    // of the scan on the stream) clears them; mode 1 (fp32 left fold for the fallback) runs only if set.
-    if (mode == 1 && flags[g.B] == 0) return;
-    if (mode == 0 && blockIdx.x == 0)
-        for (int i = threadIdx.x; i <= g.B; i += 256) flags[i] = 0;
+    // blockIdx.y = 0: direction `transposed0`; blockIdx.y = 1: the other direction (forward call that also
+    // prepares the adjoint for the backward).  Runs ahead of the scans on the stream: clears their absmax words.
+    const int transposed = blockIdx.y == 0 ? transposed0 : 1 - transposed0;
+    _Float16 *apack = blockIdx.y == 0 ? apack0 : apack1;
+    float *wf32 = blockIdx.y == 0 ? wf0 : wf1;
+    constexpr int mode = 0;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        if (zero0) *zero0 = 0u;
+        if (zero1) *zero1 = 0u;
+    }
     constexpr int NBK = C / 16, XP = C + 1; // XP: fp64 row pitch (conflict-free row- and column-wise)
     __shared__ float sL[C * C];
     __shared__ double sX[C * XP];
@@ -563,28 +582,6 @@ __global__ __launch_bounds__(256) void k_foldpack(const float *__restrict__ w, _
         }
     }
 
-    if (mode == 1) {
-        // fp32 left fold for the general scan (prep.hip k_fold layout): wf[t][kc][c], t = dh*KW+dw,
-        //   t = 0 : L^-1 (transposed: L^-T);   t > 0 : L^-1 W_t (transposed: L^-T W_t^T)
-        // slot s of this grid maps to t = (s + 1) mod NT so that the NT slots cover t = 0..NT-1
-        const int t = (s + 1) % NT, dh = t / g.KW, dw = t % g.KW;
-        for (int idx = tid; idx < 16 * C; idx += 256) {
-            const int cl = idx / C, kc = idx % C, c = 16 * rgrp + cl;
-            double acc = 0.0;
-            if (t == 0) {
-                acc = transposed ? sX[kc * XP + c] : sX[c * XP + kc];
-            } else if (!transposed) {
-                for (int m = 0; m <= c; ++m)
-                    acc += sX[c * XP + m] * (double)w[w_index2(m, kc, dh, dw, C, g.KH, g.KW, g.flipH, g.flipW)];
-            } else {
-                for (int m = c; m < C; ++m)
-                    acc += sX[m * XP + c] * (double)w[w_index2(kc, m, dh, dw, C, g.KH, g.KW, g.flipH, g.flipW)];
-            }
-            wf32[((size_t)t * C + kc) * C + c] = (float)acc;
-        }
-        return;
-    }
-
     // ---- this workgroup's 16 rows of the slot: product, split, pack ------------------------------------
     for (int idx = tid; idx < 16 * C; idx += 256) {
         const int cl = idx / C, kc = idx % C, c = 16 * rgrp + cl;
@@ -628,17 +625,16 @@ bool scan_mfma_supported(const Geom &g, const void *x, const void *z)
     return true;
 }
 
-int launch_foldpack_mfma(const float *w, void *out, float *wf32, const Geom &g, int transposed, int mode, int *flags,
-                         hipStream_t s)
+int launch_foldpack_mfma(const float *w, void *out0, float *wf0, void *out1, float *wf1, const Geom &g, int transposed,
+                         int ndir, unsigned *zero0, unsigned *zero1, hipStream_t s)
 {
-    const int blocks = g.KH * g.KW * (g.C / 16);
-    if (mode == 1) wf32 = (float *)out;
+    const dim3 grid(g.KH * g.KW * (g.C / 16), ndir);
     if (g.C == 64)
-        hipLaunchKernelGGL(k_foldpack<64>, dim3(blocks), dim3(256), 0, s, w, (_Float16 *)out, g, transposed, mode, flags,
-                           wf32);
+        hipLaunchKernelGGL(k_foldpack<64>, grid, dim3(256), 0, s, w, (_Float16 *)out0, wf0, (_Float16 *)out1, wf1, g,
+                           transposed, zero0, zero1);
     else if (g.C == 32)
-        hipLaunchKernelGGL(k_foldpack<32>, dim3(blocks), dim3(256), 0, s, w, (_Float16 *)out, g, transposed, mode, flags,
-                           wf32);
+        hipLaunchKernelGGL(k_foldpack<32>, grid, dim3(256), 0, s, w, (_Float16 *)out0, wf0, (_Float16 *)out1, wf1, g,
+                           transposed, zero0, zero1);
     else
         IFL_FAIL(IFL_EUNSUPPORTED, "launch_foldpack_mfma: C=%d", g.C);
     IFL_HIP(hipGetLastError());
@@ -647,7 +643,7 @@ int launch_foldpack_mfma(const float *w, void *out, float *wf32, const Geom &g, 
 
 template <int C, int KH, int KW, int NTILE>
 static int launch_one(const float *x, float *z, const void *apack, const Geom &g, int rh, int rw, int *flags,
-                      const float *wf32, hipStream_t s)
+                      const float *wf32, unsigned *amax, hipStream_t s)
 {
     using Cfg = ScanCfg<C, KH, KW, NTILE>;
     static_assert(Cfg::LDSB <= 160 * 1024, "ring + x staging must fit the CU's LDS");
@@ -660,17 +656,17 @@ static int launch_one(const float *x, float *z, const void *apack, const Geom &g
     if (scan_general_lds_bytes(g) > (size_t)Cfg::LDSB)
         IFL_FAIL(IFL_EUNSUPPORTED, "launch_scan_mfma: fp32 fallback does not fit the kernel's LDS");
     hipLaunchKernelGGL((k_scan_mfma<C, KH, KW, NTILE>), dim3(g.B), dim3(Cfg::THREADS), Cfg::LDSB, s, x, z,
-                       (const half8 *)apack, g.H, g.W, rh, rw, flags, wf32, g);
+                       (const half8 *)apack, g.H, g.W, rh, rw, flags, wf32, g, amax);
     IFL_HIP(hipGetLastError());
     return IFL_OK;
 }
 
 int launch_scan_mfma(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, int *flags,
-                     const float *wf32, hipStream_t s)
+                     const float *wf32, unsigned *amax, hipStream_t s)
 {
     const int nt = g.H <= 16 ? 1 : 2;
 #define IFL_CASE(CC, KK, NN) \
-    if (g.C == CC && g.KH == KK && g.KW == KK && nt == NN) return launch_one<CC, KK, KK, NN>(x, z, apack, g, rh, rw, flags, wf32, s);
+    if (g.C == CC && g.KH == KK && g.KW == KK && nt == NN) return launch_one<CC, KK, KK, NN>(x, z, apack, g, rh, rw, flags, wf32, amax, s);
     IFL_CASE(64, 3, 1)
     IFL_CASE(64, 3, 2)
     IFL_CASE(32, 3, 1)

@@ -122,8 +122,9 @@ template <int J> __device__ __forceinline__ half8 shift_frag(const half8 &f, uns
 // C channels, KHxKW taps (KW <= 3), NKS = W/16 k-steps per image row
 template <int C, int KH, int KW, int NKS>
 __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a, const float *__restrict__ bb,
-                                                    float *__restrict__ partial, const unsigned *__restrict__ absmax,
-                                                    int a_is_first, int B, int H, int sg, int ntask)
+                                                    float *__restrict__ partial, const unsigned *__restrict__ amax_a,
+                                                    const unsigned *__restrict__ amax_b, int B, int H, int sg,
+                                                    int ntask)
 {
     constexpr int W = 16 * NKS;
     constexpr int NT = KH * KW;
@@ -135,9 +136,9 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
     const int blk = blockIdx.x % (NB * NB), split = blockIdx.x / (NB * NB);
     const int bp = blk / NB, bq = blk % NB; // block row (a channels) / column (bb channels)
 
-    // absmax[0] belongs to the tensor passed first to the launcher (gz), [1] to the second (x)
-    const float sa = pow2_scale(absmax[a_is_first ? 0 : 1]);
-    const float sb = pow2_scale(absmax[a_is_first ? 1 : 0]);
+    // max|a|, max|bb| as float bit patterns (upper bounds are fine: they only pick a power-of-two scale)
+    const float sa = pow2_scale(*amax_a);
+    const float sb = pow2_scale(*amax_b);
 
     floatx16 acc[NT];
 #pragma unroll
@@ -306,13 +307,14 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
 // dw[co][ci][kh][kw] = scale/(sa*sb) * sum_splits partial[s][t=(i,j)][p][q], p/q = (co,ci) or (ci,co).
 // Four lanes share one output (each sums every 4th partial, then a fixed-order butterfly): deterministic.
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ partial, float *__restrict__ dw,
-                                                      const unsigned *__restrict__ absmax, int nsplit, int C, int KH,
+                                                      const unsigned *__restrict__ amax_a,
+                                                      const unsigned *__restrict__ amax_b, int nsplit, int C, int KH,
                                                       int KW, int swapped, int top, int left, float scale,
                                                       int mask_mode, int mkh, int mkw)
 {
     const int NT = KH * KW;
     const size_t total = (size_t)NT * C * C;
-    const float inv = scale / (pow2_scale(absmax[0]) * pow2_scale(absmax[1]));
+    const float inv = scale / (pow2_scale(*amax_a) * pow2_scale(*amax_b));
     const int sub = threadIdx.x >> 6;                                    // wave index = partial residue class
     const size_t idx = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);     // output element
     __shared__ float red[4][64];
@@ -337,6 +339,18 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
     }
 }
 
+int launch_absmax(const float *a, size_t n, unsigned *out, hipStream_t s)
+{
+    // out[0] <- max|a|; the second result of k_absmax2 goes to the spare word behind it (carry header slack)
+    IFL_HIP(hipMemsetAsync(out, 0, 2 * sizeof(unsigned), s));
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_absmax2, dim3((unsigned)blocks), dim3(256), 0, s, a, a, n, out);
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+
 bool wgrad_mfma_supported(int B, int C, int H, int W, int KH, int KW, int pt, int pl, const void *gz, const void *x)
 {
     if (!(C == 32 || C == 64)) return false;
@@ -359,8 +373,8 @@ size_t wgrad_mfma_workspace_bytes(int B, int C, int H, int KH, int KW)
 }
 
 template <int C, int KH, int KW, int NKS>
-static int launch_wg(const float *a, const float *bb, float *partial, const unsigned *absmax, int a_is_first, int B,
-                     int H, int sg, hipStream_t s)
+static int launch_wg(const float *a, const float *bb, float *partial, const unsigned *amax_a, const unsigned *amax_b,
+                     int B, int H, int sg, hipStream_t s)
 {
     const int ntask = wgrad_ntask(B, H);
     const int nsplit = (ntask + 3) / 4;
@@ -372,25 +386,29 @@ static int launch_wg(const float *a, const float *bb, float *partial, const unsi
                                     (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_wgrad_mfma<C, KH, KW, NKS>), dim3(nsplit * NB * NB), dim3(256), lds, s, a, bb, partial, absmax,
-                       a_is_first, B, H, sg, ntask);
+    hipLaunchKernelGGL((k_wgrad_mfma<C, KH, KW, NKS>), dim3(nsplit * NB * NB), dim3(256), lds, s, a, bb, partial, amax_a,
+                       amax_b, B, H, sg, ntask);
     IFL_HIP(hipGetLastError());
     return IFL_OK;
 }
 
 int launch_wgrad_mfma(const float *gz, const float *x, float *dw, void *ws, int B, int C, int H, int W, int KH, int KW,
-                      int pt, int pl, float scale, int mask_mode, int mkh, int mkw, hipStream_t s)
+                      int pt, int pl, float scale, int mask_mode, int mkh, int mkw, const unsigned *amax_gz,
+                      const unsigned *amax_x, hipStream_t s)
 {
     unsigned *absmax = (unsigned *)ws;
     float *partial = (float *)((char *)ws + 256);
     const size_t n = (size_t)B * C * H * W;
-    IFL_HIP(hipMemsetAsync(absmax, 0, 2 * sizeof(unsigned), s));
-    {
+    if (!amax_gz || !amax_x) {
+        // no producer handed the maxima over: one streaming pass over both tensors
+        IFL_HIP(hipMemsetAsync(absmax, 0, 2 * sizeof(unsigned), s));
         size_t blocks = (n / 4 + 255) / 256;
         if (blocks > 512) blocks = 512;
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(k_absmax2, dim3((unsigned)blocks), dim3(256), 0, s, gz, x, n, absmax);
         IFL_HIP(hipGetLastError());
+        amax_gz = absmax;
+        amax_x = absmax + 1;
     }
     const int top = pt != 0, left = pl != 0;
     // canonical form (see header): L orders shift gz, R orders shift x and transpose the result
@@ -399,7 +417,7 @@ int launch_wgrad_mfma(const float *gz, const float *x, float *dw, void *ws, int 
     const int sg = (top != swapped) ? +1 : -1; // TL:+1  BL:-1  TR:-1  BR:+1
     int rc = IFL_EUNSUPPORTED;
 #define IFL_CASE(CC, KK, NN) \
-    if (C == CC && KH == KK && W == 16 * NN) rc = launch_wg<CC, KK, KK, NN>(a, bb, partial, absmax, swapped ? 0 : 1, B, H, sg, s);
+    if (C == CC && KH == KK && W == 16 * NN) rc = launch_wg<CC, KK, KK, NN>(a, bb, partial, swapped ? amax_x : amax_gz, swapped ? amax_gz : amax_x, B, H, sg, s);
     IFL_CASE(64, 3, 2)
     IFL_CASE(64, 3, 1)
     IFL_CASE(32, 3, 2)
@@ -414,7 +432,7 @@ int launch_wgrad_mfma(const float *gz, const float *x, float *dw, void *ws, int 
     const int nsplit = (wgrad_ntask(B, H) + 3) / 4;
     const size_t total = (size_t)KH * KW * C * C;
     size_t blocks = (total + 63) / 64;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)blocks), dim3(256), 0, s, partial, dw, absmax, nsplit, C, KH, KW,
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)blocks), dim3(256), 0, s, partial, dw, amax_gz, amax_x, nsplit, C, KH, KW,
                        swapped, top, left, scale, mask_mode, mkh, mkw);
     IFL_HIP(hipGetLastError());
     return IFL_OK;

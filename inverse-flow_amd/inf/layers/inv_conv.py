@@ -39,8 +39,14 @@ class inv_conv_(torch.autograd.Function):
     def forward(ctx, x, W, order="TL", flags=0, recon_weight=0.0):
         x = x.contiguous()
         Wc = W.contiguous()
-        z = _h.inverse(x, Wc, order, flags)
+        need_bwd = any(ctx.needs_input_grad[:2])
+        # side channel of this step: adjoint weights + max|z| from the forward, so the backward neither folds
+        # again nor scans z and dx (ifl_carry_bytes, include/invflow.h)
+        carry = _h.new_carry(Wc) if need_bwd else None
+        z = _h.inverse(x, Wc, order, flags, carry=carry)
         ctx.order, ctx.flags, ctx.recon_weight = order, flags, float(recon_weight)
+        ctx.carry = carry
+        ctx.w_version = Wc._version
         if recon_weight != 0.0:
             ctx.save_for_backward(Wc, z, x)
         else:
@@ -55,7 +61,8 @@ class inv_conv_(torch.autograd.Function):
         x = saved[2] if len(saved) > 2 else None
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dx, dw, rl = _h.backward(output_grad.contiguous(), z, Wc, ctx.order, ctx.flags, x=x,
-                                 recon_weight=ctx.recon_weight, need_dx=need_dx, need_dw=need_dw)
+                                 recon_weight=ctx.recon_weight, need_dx=need_dx, need_dw=need_dw,
+                                 carry=ctx.carry if Wc._version == ctx.w_version else None)
         ctx.recon_loss = rl
         return dx, dw, None, None, None
 

@@ -30,9 +30,10 @@ SIGNATURES = {
     "ifl_profile_enable": (None, [_i]),
     "ifl_profile_collect": (_i, [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i)]),
     "ifl_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _u]),
-    "ifl_inverse_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
+    "ifl_inverse_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp]),
+    "ifl_carry_bytes": (_sz, [_i, _i, _i]),
     "ifl_forward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
-    "ifl_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
+    "ifl_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp]),
     "ifl_dw_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "ifl_conv2d_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ifl_conv2d_wgrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
@@ -128,8 +129,16 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def inverse(x, w, order="TL", flags=0, out=None):
-    """z = A^-1 x.  Replaces inv_conv_with_bp.inverse (inv_conv_with_bp_general.cpp:19-28)."""
+def new_carry(w):
+    """Buffer for the forward -> backward side channel of one step (see ifl_carry_bytes in invflow.h)."""
+    C, _, KH, KW = w.shape
+    return torch.empty(int(lib().ifl_carry_bytes(C, KH, KW)), dtype=torch.uint8, device=w.device)
+
+
+def inverse(x, w, order="TL", flags=0, out=None, carry=None):
+    """z = A^-1 x.  Replaces inv_conv_with_bp.inverse (inv_conv_with_bp_general.cpp:19-28).
+
+    `carry` (from new_carry) is filled for the backward call of the same step."""
     _chk_tensor(x, "input")
     _chk_tensor(w, "kernel")
     B, C, H, W, KH, KW = _shape5(x, w)
@@ -145,7 +154,7 @@ def inverse(x, w, order="TL", flags=0, out=None):
         nb = L.ifl_workspace_bytes(OP_INVERSE, B, C, H, W, KH, KW, flags)
         ws = _ws(nb, dev)
         rc = L.ifl_inverse_f32(_ptr(x), _ptr(w), _ptr(out), B, C, H, W, KH, KW, _order(order), flags, _ptr(ws), nb,
-                               torch.cuda.current_stream().cuda_stream)
+                               _ptr(carry), torch.cuda.current_stream().cuda_stream)
     _check(rc, "ifl_inverse_f32")
     return out
 
@@ -174,7 +183,7 @@ def forward(z, w, order="TL", flags=0, out=None, want_logdet=False):
 
 
 def backward(g, z, w, order="TL", flags=0, x=None, recon_weight=0.0, need_dx=True, need_dw=True,
-             dx_out=None, dw_out=None):
+             dx_out=None, dw_out=None, carry=None):
     """Fused backward: dx = A^-T g, dw = -(sum dx (x) shifted z)*mask [+ recon term].
 
     Replaces inv_conv_with_bp.dy + inv_conv_with_bp.dw (…general.cpp:70-112).  Returns
@@ -210,7 +219,8 @@ def backward(g, z, w, order="TL", flags=0, x=None, recon_weight=0.0, need_dx=Tru
         ws = _ws(nb, dev)
         rc = L.ifl_backward_f32(_ptr(g), _ptr(z) if need_dw else None, _ptr(x) if recon else None, _ptr(w), _ptr(dx),
                                 _ptr(dw), float(recon_weight) if recon else 0.0, _ptr(rl), B, C, H, W, KH, KW,
-                                _order(order), flags, _ptr(ws), nb, torch.cuda.current_stream().cuda_stream)
+                                _order(order), flags, _ptr(ws), nb, _ptr(carry),
+                                torch.cuda.current_stream().cuda_stream)
     _check(rc, "ifl_backward_f32")
     return dx, dw, rl
 

@@ -47,21 +47,22 @@ def test_version_and_workspace(H):
     assert L.ifl_workspace_bytes(H.OP_INVERSE, 128, 64, 32, 32, 3, 3, 0) >= 64 * 64 * 9 * 4
     assert L.ifl_workspace_bytes(H.OP_INVERSE, -1, 64, 32, 32, 3, 3, 0) == 0
     assert L.ifl_conv2d_workspace_bytes(8, 4, 4, 8, 8, 3, 3, 1, 1) >= 4 * 4 * 9 * 4
+    assert L.ifl_carry_bytes(64, 3, 3) >= 256 + 2 * 64 * 64 * 9 * 4 and L.ifl_carry_bytes(0, 3, 3) == 0
 
 
 def test_argument_validation_without_gpu(H):
     L = H.lib()
     # bad shape -> IFL_EINVAL with a message, nothing is launched
-    rc = L.ifl_inverse_f32(None, None, None, 2, 0, 5, 5, 3, 3, 0, 0, None, 0, None)
+    rc = L.ifl_inverse_f32(None, None, None, 2, 0, 5, 5, 3, 3, 0, 0, None, 0, None, None)
     assert rc == -1 and b"bad shape" in L.ifl_last_error()
-    rc = L.ifl_inverse_f32(None, None, None, 2, 4, 5, 5, 3, 3, 7, 0, None, 0, None)
+    rc = L.ifl_inverse_f32(None, None, None, 2, 4, 5, 5, 3, 3, 7, 0, None, 0, None, None)
     assert rc == -1 and b"unknown order" in L.ifl_last_error()
     # empty batch is a no-op success and clears the error
-    assert L.ifl_inverse_f32(None, None, None, 0, 4, 5, 5, 3, 3, 0, 0, None, 0, None) == 0
+    assert L.ifl_inverse_f32(None, None, None, 0, 4, 5, 5, 3, 3, 0, 0, None, 0, None, None) == 0
     assert L.ifl_last_error() == b""
     assert L.ifl_forward_f32(None, None, None, None, 0, 4, 5, 5, 3, 3, 0, 0, None, 0, None) == 0
     # null tensors with a non-empty batch
-    rc = L.ifl_inverse_f32(None, None, None, 1, 4, 5, 5, 3, 3, 0, 0, None, 0, None)
+    rc = L.ifl_inverse_f32(None, None, None, 1, 4, 5, 5, 3, 3, 0, 0, None, 0, None, None)
     assert rc == -1 and b"null tensor" in L.ifl_last_error()
     rc = L.ifl_conv2d_f32(None, None, None, None, 1, 4, 4, 2, 2, 3, 3, 0, 0, None)
     assert rc == -1 and b"kernel larger" in L.ifl_last_error()

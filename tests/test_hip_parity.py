@@ -210,6 +210,28 @@ def test_full_size_properties(H, oracle):
     assert torch.equal(z, z2) and torch.equal(dx, dx2) and torch.equal(dw, dw2)
 
 
+def test_carry_side_channel_is_transparent(H, oracle):
+    """The forward -> backward carry (adjoint fold + maxima) must not change any result."""
+    rng = np.random.default_rng(21)
+    for (B, C, S, K, order) in [(4, 64, 32, 3, "TL"), (3, 32, 16, 2, "BR"), (2, 8, 8, 3, "TL")]:
+        w = dev(_weights(rng, C, K, K, "refinit", order, oracle))
+        x = torch.randn(B, C, S, S, device="cuda")
+        g = torch.randn(B, C, S, S, device="cuda") * 1e-3  # small gradients: the dx prescale matters
+        z0 = H.inverse(x, w, order)
+        dx0, dw0, _ = H.backward(g, z0, w, order)
+        carry = H.new_carry(w)
+        z1 = H.inverse(x, w, order, carry=carry)
+        dx1, dw1, _ = H.backward(g, z1, w, order, carry=carry)
+        assert torch.equal(z0, z1) and torch.equal(dx0, dx1)
+        assert float((dw0 - dw1).norm() / dw0.norm()) < 1e-6
+        u_o = oracle.dy(host(g), host(w), 0, order, nthreads=8)
+        dw_o = oracle.dw(host(z0), u_o, (K, K), 0, order, nthreads=8)
+        assert rel_err(host(dw1), dw_o) < TOL
+        # a second backward with the same carry (retain_graph) still works
+        dx2, dw2, _ = H.backward(g, z1, w, order, carry=carry)
+        assert torch.equal(dx1, dx2) and rel_err(host(dw2), dw_o) < TOL
+
+
 def test_empty_batch_and_errors(H):
     w = torch.zeros(4, 4, 3, 3, device="cuda")
     x = torch.zeros(0, 4, 5, 5, device="cuda")

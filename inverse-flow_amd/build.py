@@ -19,7 +19,7 @@ LIB = os.path.join(LIBDIR, "libinvflow_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
-         "-ffp-contract=fast"]
+         "-ffp-contract=fast"] + os.environ.get("HIPCC_EXTRA", "").split()
 
 
 def _newer(a, b):

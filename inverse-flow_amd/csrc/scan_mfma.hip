@@ -36,6 +36,7 @@
 
 #include "ifl_common.h"
 #include "scan_general_body.h"
+#include <stdlib.h>
 
 namespace ifl {
 
@@ -48,24 +49,21 @@ static constexpr float LO_INV = 1.0f / 2048.0f;
 
 template <int C, int KH, int KW, int NTILE> struct ScanCfg {
     static constexpr int NW = C / 16;      // 16-channel output groups
-    static constexpr int NWAVES = NW * NTILE; // one wave per (row tile, channel group): two waves per SIMD at 32 rows
+    static constexpr int NWAVES = NW;      // one wave per channel group (one per SIMD at C=64), all row tiles: 512 registers
     static constexpr int NQ = C / 32;      // 32-deep k-steps per tap
     static constexpr int NT = KH * KW;     // taps incl. the diagonal one
     static constexpr int NS = NT;          // A slots: NT-1 folded taps + 1 post matrix (L^-1)
-    static constexpr int R = KH + KW - 1;  // r-ring depth (current + KH+KW-2 previous diagonals)
+    static constexpr int R = 2;            // r-ring depth: the diagonal being written and the previous one (push form)
+    static constexpr int NACC = 3;         // rolling accumulators: diagonals d, d+1, d+2 (rotated by register moves each step)
+    static_assert(KH + KW - 2 <= 4 && KH <= 3, "push scan: taps reach at most 4 diagonals ahead, 2 rows up");
     static constexpr int NPL = NQ * 8;     // planes per row block: (k-step, hi/lo, k-group)
     static constexpr int RBB = NPL * 256;  // bytes of one row block (16 rows x NPL planes x 16 B)
-    static constexpr int SLOTB = NTILE * RBB;
+    static constexpr int SLOTB = (NTILE + 1) * RBB; // one diagonal: an always-zero block (sources above the image) + the tiles
     static constexpr int RINGB = R * SLOTB;
-    static constexpr int ZEROB = RBB;      // always-zero block read for sources above the image
-    static constexpr int XROWB = 2 * C * 16 + 16; // x quads of one row: [parity][channel] + pad
+    static constexpr int XROWB = 2 * C * 16 + 16; // quads of one row: [parity][channel][4] + pad (x staging and z staging)
     static constexpr int XSB = 16 * NTILE * XROWB;
-    static constexpr int RZ = 5;           // z-ring depth: a quad's 4 diagonals + the one being written
-    static constexpr int ZROWB = C * 4 + 16;
-    static constexpr int ZSLOTB = 16 * NTILE * ZROWB;
-    static constexpr int ZRINGB = RZ * ZSLOTB;
-    static constexpr int OFF_ZERO = RINGB, OFF_XS = OFF_ZERO + ZEROB, OFF_ZR = OFF_XS + XSB;
-    static constexpr int LDSB = OFF_ZR + ZRINGB;
+    static constexpr int OFF_XS = RINGB, OFF_ZQ = OFF_XS + XSB;
+    static constexpr int LDSB = OFF_ZQ + XSB;
     static constexpr int THREADS = 64 * NWAVES;
     static constexpr int ROWS_PER_ITER = 4 * NTILE; // rows that start/finish a quad each step
     static constexpr int G = ROWS_PER_ITER / NWAVES; // ... per wave: DMA (and at most as many store) instructions
@@ -82,9 +80,38 @@ __device__ __forceinline__ void lds_read_b128(half8 &v, unsigned addr)
 {
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
 }
+// ... with the constant part of the address in the instruction's offset field (one address register per row shift)
+template <int OFF> __device__ __forceinline__ void lds_read_b128_o(half8 &v, unsigned addr)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+// the hi and lo planes of all k-steps of one fragment set
+template <int NQ, int OFF> __device__ __forceinline__ void lds_read_set(half8 (&h)[NQ], half8 (&l)[NQ], unsigned addr)
+{
+    lds_read_b128_o<OFF>(h[0], addr);
+    lds_read_b128_o<OFF + 4 * 256>(l[0], addr);
+    if constexpr (NQ == 2) {
+        lds_read_b128_o<OFF + 8 * 256>(h[1], addr);
+        lds_read_b128_o<OFF + 12 * 256>(l[1], addr);
+    }
+}
 template <int N> __device__ __forceinline__ void lgkm_wait(half8 &a, half8 &b)
 {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+
+// counted LDS wait with a compile-time-foldable argument
+__device__ __forceinline__ void lgkm_wait_n(int n)
+{
+#define IFL_L(N) \
+    case N: asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); break;
+    switch (n < 0 ? 0 : (n > 15 ? 15 : n)) {
+        IFL_L(0) IFL_L(1) IFL_L(2) IFL_L(3) IFL_L(4) IFL_L(5) IFL_L(6) IFL_L(7) IFL_L(8) IFL_L(9) IFL_L(10) IFL_L(11)
+        IFL_L(12) IFL_L(13) IFL_L(14) IFL_L(15)
+    }
+#undef IFL_L
+    __builtin_amdgcn_sched_barrier(0); // nothing that consumes the data may be scheduled above the wait
 }
 
 // "all but the n youngest vector-memory operations of this wave are complete", LDS drained, then the
@@ -102,8 +129,25 @@ __device__ __forceinline__ void wait_vm_then_barrier(int n)
 #undef IFL_W
 }
 
+// Development aid (tools/stamps.py; build with HIPCC_EXTRA=-DIFL_STAMPS): per-wave cycle counts of the sections
+// of a step, summed over the steps of workgroup 0.  Compiled out of the product build.
+#ifdef IFL_STAMPS
+__device__ unsigned long long *g_stamps = nullptr;
+#define IFL_STAMP(k)                                            \
+    do {                                                        \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+        st_acc[k] += t_ - st_last;                              \
+        st_last = t_;                                           \
+    } while (0)
+#else
+#define IFL_STAMP(k) \
+    do {             \
+    } while (0)
+#endif
+
 template <int C, int KH, int KW, int NTILE>
-__global__ __launch_bounds__(64 * (C / 16) * NTILE) void k_scan_mfma(const float *__restrict__ xin,
+__global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__restrict__ xin,
                                                                     float *__restrict__ zout,
                                                                     const half8 *__restrict__ apack, int H, int W,
                                                                     int rh, int rw, int *__restrict__ flags,
@@ -111,17 +155,15 @@ __global__ __launch_bounds__(64 * (C / 16) * NTILE) void k_scan_mfma(const float
                                                                     unsigned *__restrict__ amax)
 {
     using Cfg = ScanCfg<C, KH, KW, NTILE>;
-    constexpr int NQ = Cfg::NQ, NT = Cfg::NT, NS = Cfg::NS, R = Cfg::R, RBB = Cfg::RBB, SLOTB = Cfg::SLOTB,
-                  RZ = Cfg::RZ, G = Cfg::G, NW = Cfg::NW;
+    constexpr int NQ = Cfg::NQ, NS = Cfg::NS, RBB = Cfg::RBB, SLOTB = Cfg::SLOTB, G = Cfg::G;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char *ring = lds;
     unsigned char *xs = lds + Cfg::OFF_XS;
-    unsigned char *zr = lds + Cfg::OFF_ZR;
+    unsigned char *zq = lds + Cfg::OFF_ZQ;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index: scalar
-    const int wv = wave % NW; // 16-channel output group of this wave
-    const int T = wave / NW;  // 16-row tile of this wave
+    const int wv = wave; // 16-channel output group of this wave
     const int n = lane & 15, g = lane >> 4;
     const int b = blockIdx.x;
     const int ND = H + W - 1;
@@ -129,7 +171,7 @@ __global__ __launch_bounds__(64 * (C / 16) * NTILE) void k_scan_mfma(const float
     // ---- zero the r-ring and the zero block (zero padding of the operator) ---------------------------
     {
         const floatx4 zz = {0.f, 0.f, 0.f, 0.f};
-        for (int i = tid * 16; i < Cfg::OFF_XS; i += Cfg::THREADS * 16) *(floatx4 *)(lds + i) = zz;
+        for (int i = tid * 16; i < Cfg::RINGB; i += Cfg::THREADS * 16) *(floatx4 *)(lds + i) = zz;
     }
 
     // ---- folded weights -> registers (A fragments, hi and lo) -----------------------------------
@@ -146,302 +188,284 @@ __global__ __launch_bounds__(64 * (C / 16) * NTILE) void k_scan_mfma(const float
                 asm volatile("" : "+a"(A[s][q][hl]));
             }
 
-    // ---- per-lane constants -------------------------------------------------------------------
-    // compute role: lane (n, g) owns pixel row h = 16T+n and channels c0..c0+3 (C/D layout)
+    // ---- per-lane constants: lane (n, g) owns pixel rows h = 16T+n and channels c0..c0+3 (C/D layout) ----
     const int c0 = 16 * wv + 4 * g;
-    const int h = 16 * T + n;
-    const bool hval = h < H;
-    int radr[KH]; // slot-relative LDS offset of this lane's B piece for a source dh rows up (plane 0 of its g)
-    bool rzero[KH]; // the source row is above the image
-#pragma unroll
-    for (int dh = 0; dh < KH; ++dh) {
-        const int hs = h - dh;
-        rzero[dh] = hs < 0;
-        radr[dh] = hs >= 0 ? (hs / 16) * RBB + g * 256 + (hs % 16) * 16 : 0;
-    }
-    const int wadr = T * RBB + (((c0 / 32) * 2) * 4 + (c0 % 32) / 8) * 256 + n * 16 + ((c0 % 8) / 4) * 8;
-    const int xadr = h * Cfg::XROWB + c0 * 16;
-    const int zadr = h * Cfg::ZROWB + c0 * 4;
-    const int zbase = Cfg::OFF_ZERO + g * 256 + n * 16; // this lane's piece in the zero block
     const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    unsigned radr[NTILE][KH]; // LDS address (slot 0) of this lane's B piece for a source dh rows up
+    int wadr[NTILE], xadr[NTILE];
+    bool hval[NTILE];
+#pragma unroll
+    for (int T = 0; T < NTILE; ++T) {
+        const int h = 16 * T + n;
+        hval[T] = h < H;
+#pragma unroll
+        for (int dh = 0; dh < KH; ++dh) {
+            const int hs = h - dh + 16; // row block 0 of a slot is the zero block
+            radr[T][dh] = ldsbase + (hs / 16) * RBB + g * 256 + (hs % 16) * 16;
+        }
+        wadr[T] = (T + 1) * RBB + (((c0 / 32) * 2) * 4 + (c0 % 32) / 8) * 256 + n * 16 + ((c0 % 8) / 4) * 8;
+        xadr[T] = h * Cfg::XROWB + c0 * 16;
+    }
 
     // DMA / store role: lane = channel, G rows per wave and step
     const int cl = lane < C ? lane : 0;
     const unsigned voff = (unsigned)((size_t)cl * H * W * sizeof(float)); // per-lane byte offset of its channel
     const char *xg = (const char *)xin + (size_t)b * C * H * W * sizeof(float);
     char *zg = (char *)zout + (size_t)b * C * H * W * sizeof(float);
+    // byte offset of the quad (row hr, columns wq..wq+3) in a stored channel plane = gbase + hr*grow + wq*gcol
+    const int grow = rh ? -4 * W : 4 * W, gcol = rw ? -4 : 4;
+    const int gbase = (rh ? (H - 1) * 4 * W : 0) + (rw ? (W - 4) * 4 : 0);
 
-    // soff[k] / zoff[k]: LDS offsets of the slots holding diagonal d-k (r) and d-1-k (z)
-    int soff[R], zoff[RZ];
-#pragma unroll
-    for (int k = 0; k < R; ++k) soff[k] = ((R - k) % R) * SLOTB;
-#pragma unroll
-    for (int k = 0; k < RZ; ++k) zoff[k] = ((RZ - k) % RZ) * Cfg::ZSLOTB;
     int nst[3] = {0, 0, 0}; // store instructions this wave issued in the previous three steps
-    bool ovf = false;       // an r of this lane left the fp16 range (or is not a number)
+    float rmax = 0.f;       // max |r| this lane put into the ring: beyond the fp16 range the image is redone in fp32
     float zmax = 0.f;       // max |z| this lane stored (handed to the weight-gradient kernel as its prescale)
+    int qprev = 0;          // in-row staging offset (parity, position in the quad) of the previous step's column
 
+    // Rolling accumulators ("push" form): acc[k] collects everything the taps contribute to diagonal d+k; the
+    // step that finishes diagonal d only adds the two taps whose source is r_{d-1}.
+    floatx4 ahi[NTILE][Cfg::NACC], amid[NTILE][Cfg::NACC];
+    // fragments of the source rows two up (dh = 2), carried to the next step.  Single-buffered: the reload is
+    // issued after the MFMAs that read them have been issued (operands are read at issue).
+    half8 F2h[NTILE][NQ], F2l[NTILE][NQ];
+#pragma unroll
+    for (int T = 0; T < NTILE; ++T) {
+#pragma unroll
+        for (int k = 0; k < Cfg::NACC; ++k) {
+            ahi[T][k] = floatx4{0.f, 0.f, 0.f, 0.f};
+            amid[T][k] = floatx4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                F2h[T][q][j] = (_Float16)0.f;
+                F2l[T][q][j] = (_Float16)0.f;
+            }
+    }
+
+#ifdef IFL_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
 
-    // One step of the scan, specialised on whether this wave's tile holds pixels of diagonal d, so that
-    // the body is straight-line code; LDS fragment reads run one (tap, k-step) unit ahead of the MFMAs
-    // that consume them.  With 32 image rows two waves share a SIMD (one per row tile): one wave's LDS
-    // latency is covered by the other's MFMAs.
-    auto step = [&](auto act_c, const int d) {
-        constexpr bool ACT = decltype(act_c)::value;
-        const int ph = (((d - 1) % 4) + 4) % 4; // rows h = ph (mod 4) are one step into a quad of x
+    // One step, specialised on the set of tiles in their active window.  Source diagonal d-1 is read from LDS
+    // ONCE (three row-shifted fragment sets per tile); each tap pushes it into the accumulator of the diagonal
+    // it lands on:
+    //   leading  : the dh=2 taps of r_{d-2} (fragments kept in registers from the previous step) -- they fill
+    //              the matrix pipe while this step's fragment reads are in flight,
+    //   critical : the two taps whose target is diagonal d itself, then r_d = x + acc -> ring  (the chain),
+    //   trailing : the other taps of r_{d-1} and the z product, behind the epilogue.
+    // The scan is bound by instruction issue (one wave per SIMD), so everything around the MFMAs is kept short:
+    // 32-bit scalar address arithmetic, one staging layout for x and z, no per-element selects.
+    auto step = [&](auto mask_c, const int d) {
+        constexpr int MASK = decltype(mask_c)::value;
+        constexpr int NA = (MASK & 1) + ((MASK >> 1) & 1);
+        const int srcoff = ((d + 1) & 1) * SLOTB; // ring slot of diagonal d-1 (slot = diagonal mod 2)
+        const int dstoff = (d & 1) * SLOTB;       // ring slot of diagonal d
+        const int ph = (d - 1) & 3;               // rows h = ph (mod 4) are one step into a quad of x
+        IFL_STAMP(7); // loop control
 
-        // ---- x quads needed three steps from now: rows at w = d-h = 1 (mod 4) fetch their next quad.
-        //      The slot-mate (two quads back) was last read in phase C of step d-2, which every wave
-        //      left before the barrier of step d-1.  Issued unconditionally (out-of-range rows load a
-        //      valid dummy) so that the number of VM operations per step is exact.
+        // ---- x quads needed three steps from now (unconditional: exact VM operation count) ----------------
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int hr = ph + 4 * (wave * G + i);
             const int wq = d - hr + 3;
-            const bool ok = hr < H && wq >= 0 && wq < W;
-            const int hc = ok ? hr : 0, wc = ok ? wq : 0;
-            const int hs = rh ? H - 1 - hc : hc;
-            const int ws = rw ? W - 4 - wc : wc;
-            const char *src = xg + ((size_t)hs * W + ws) * sizeof(float); // wave-uniform
+            const bool ok = hr < H && (unsigned)wq < (unsigned)W;
+            const int off = ok ? gbase + hr * grow + wq * gcol : 0;
+            const char *src = xg + off; // wave-uniform
             unsigned char *dst = xs + hr * Cfg::XROWB + ((wq >> 2) & 1) * (C * 16); // lane c lands at +16c
             if (C == 64 || lane < C)
                 __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + voff),
                                                  (void __attribute__((address_space(3))) *)dst, 16, 0, 0);
         }
 
-        // two accumulator chains: hi*hi and the 2^-11-scaled cross terms hi*lo' + lo'*hi (a third chain for
-        // the second cross term measured slower in the full kernel although faster in isolation)
-        floatx4 ahi = {0.f, 0.f, 0.f, 0.f}, amid = {0.f, 0.f, 0.f, 0.f};
-
-        // (tap, k-step) units of a phase.  SEL 0: taps two or more diagonals back (no dependence on step
-        // d-1), SEL 1: the two taps on diagonal d-1.
-        auto unit_count = [](int sel) {
-            int c = 0;
-            for (int t = 1; t < NT; ++t) {
-                const int s2 = t / KW + t % KW;
-                if (sel ? s2 == 1 : s2 >= 2) c += NQ;
-            }
-            return c;
-        };
-        auto unit_tap = [](int sel, int u) {
-            int c = 0;
-            for (int t = 1; t < NT; ++t) {
-                const int s2 = t / KW + t % KW;
-                if (sel ? s2 == 1 : s2 >= 2) {
-                    if (u < c + NQ) return t;
-                    c += NQ;
-                }
-            }
-            return 1;
-        };
-        auto unit_q = [](int sel, int u) {
-            int c = 0;
-            for (int t = 1; t < NT; ++t) {
-                const int s2 = t / KW + t % KW;
-                if (sel ? s2 == 1 : s2 >= 2) {
-                    if (u < c + NQ) return u - c;
-                    c += NQ;
-                }
-            }
-            return 0;
-        };
-        auto load_frag = [&](int sel, int u, half8 &vh, half8 &vl) {
-            const int t = unit_tap(sel, u), q = unit_q(sel, u), dh = t / KW, dw = t % KW;
-            int a = soff[dh + dw] + radr[dh];
-            if (dh > 0) a = rzero[dh] ? zbase : a;
-            lds_read_b128(vh, ldsbase + a + (q * 2) * 4 * 256);
-            lds_read_b128(vl, ldsbase + a + (q * 2 + 1) * 4 * 256);
-        };
-        auto mfma3 = [&](int sel, int u, const half8 &vh, const half8 &vl) {
-            const int t = unit_tap(sel, u), q = unit_q(sel, u);
-            ahi = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], vh, ahi, 0, 0, 0);
-            amid = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], vl, amid, 0, 0, 0);
-            amid = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][1], vh, amid, 0, 0, 0);
-        };
-
-        // ---- (B) old taps: a PF-deep register ring of fragments keeps the LDS latency (a few hundred
-        //      cycles with eight waves reading) off the MFMA stream -------------------------------------
-        constexpr int NUB = unit_count(0), NUC = unit_count(1);
-        constexpr int PF = NUB < 6 ? (NUB > 0 ? NUB : 1) : 6;
-        if constexpr (ACT && NUB > 0) {
-            half8 fh[PF], fl[PF];
-#pragma unroll
-            for (int u = 0; u < PF; ++u) load_frag(0, u, fh[u], fl[u]);
-            // hipcc's scheduler otherwise sinks every read down to its first use (no prefetch at all):
-            // pin the source order of reads and MFMAs
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < NUB; ++u) {
-                // reads issued so far: units < min(NUB, u+PF); unit u is the oldest outstanding one
-                {
-                    const int issued = (u + PF < NUB ? u + PF : NUB);
-                    const int allow = 2 * (issued - u - 1);
-                    switch (allow) {
-                    case 0: lgkm_wait<0>(fh[u % PF], fl[u % PF]); break;
-                    case 2: lgkm_wait<2>(fh[u % PF], fl[u % PF]); break;
-                    case 4: lgkm_wait<4>(fh[u % PF], fl[u % PF]); break;
-                    case 6: lgkm_wait<6>(fh[u % PF], fl[u % PF]); break;
-                    case 8: lgkm_wait<8>(fh[u % PF], fl[u % PF]); break;
-                    default: lgkm_wait<10>(fh[u % PF], fl[u % PF]); break;
-                    }
-                }
-                mfma3(0, u, fh[u % PF], fl[u % PF]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (u + PF < NUB) {
-                    load_frag(0, u + PF, fh[u % PF], fl[u % PF]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-
-        // The quads this wave DMA'd three steps ago must have landed before anyone reads them in phase C:
+        // The quads this wave DMA'd three steps ago must have landed before anyone reads them below:
         // younger than those are exactly the stores of steps d-3..d-1 and the DMAs of steps d-2..d.
         // Then the barrier: r of diagonal d-1 (and z of diagonal d-2) are complete in LDS.
+        IFL_STAMP(0); // DMA issue
         wait_vm_then_barrier(3 * G + nst[0] + nst[1] + nst[2]);
+        IFL_STAMP(1); // wait + barrier
 
-        // ---- (C) the two taps on diagonal d-1: all their fragments are requested at once, the MFMAs follow
-        //      with exact counted waits ---------------------------------------------------------------------
-        const int w = d - h;
-        if constexpr (ACT && NUC > 0) {
-            half8 ch[NUC], cl2[NUC];
+        auto mf = [&](int T, int t, int q, const half8 &vh, const half8 &vl, int tgt) {
+            ahi[T][tgt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], vh, ahi[T][tgt], 0, 0, 0);
+            amid[T][tgt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], vl, amid[T][tgt], 0, 0, 0);
+            amid[T][tgt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][1], vh, amid[T][tgt], 0, 0, 0);
+        };
+
+        // in-row staging offset of this step's column w = d - h: the same for all tiles (rows 16 apart)
+        const int w0 = d - n;
+        const int qcur = ((w0 >> 2) & 1) * (C * 16) + (rw ? 3 - (w0 & 3) : (w0 & 3)) * 4;
+
+        if constexpr (MASK != 0) {
+            // ---- requests: fragments of r_{d-1} for the rows 0 and 1 up, row-major so that the dh=0 sets of all
+            //      tiles land first (the dh=2 sets follow the leading MFMAs)
+            half8 Fh[NTILE][2][NQ], Fl[NTILE][2][NQ];
+            constexpr int NDH = KH < 2 ? KH : 2;
 #pragma unroll
-            for (int u = 0; u < NUC; ++u) load_frag(1, u, ch[u], cl2[u]);
+            for (int dh = 0; dh < NDH; ++dh)
+#pragma unroll
+                for (int T = 0; T < NTILE; ++T)
+                    if (MASK & (1 << T)) lds_read_set<NQ, 0>(Fh[T][dh], Fl[T][dh], radr[T][dh] + srcoff);
+            constexpr int PER = NA * NQ * 2; // reads per dh set
             __builtin_amdgcn_sched_barrier(0);
+            // ---- leading: taps (2, dw) of r_{d-2}; their targets are diagonals d-2+2+dw = d + dw -----------
+            if constexpr (KH > 2) {
 #pragma unroll
-            for (int u = 0; u < NUC; ++u) {
-                switch (2 * (NUC - 1 - u)) {
-                case 0: lgkm_wait<0>(ch[u], cl2[u]); break;
-                case 2: lgkm_wait<2>(ch[u], cl2[u]); break;
-                case 4: lgkm_wait<4>(ch[u], cl2[u]); break;
-                case 6: lgkm_wait<6>(ch[u], cl2[u]); break;
-                case 8: lgkm_wait<8>(ch[u], cl2[u]); break;
-                case 10: lgkm_wait<10>(ch[u], cl2[u]); break;
-                default: lgkm_wait<0>(ch[u], cl2[u]); break;
+                for (int dw = 0; dw < KW; ++dw)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                        for (int T = 0; T < NTILE; ++T)
+                            if (MASK & (1 << T)) mf(T, 2 * KW + dw, q, F2h[T][q], F2l[T][q], dw);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 7" ::: "memory"); // margin between the last operand read and the reload below
+                // this step's dh=2 fragments of r_{d-1}, for the next step's leading MFMAs
+#pragma unroll
+                for (int T = 0; T < NTILE; ++T)
+                    if (MASK & (1 << T)) lds_read_set<NQ, 0>(F2h[T], F2l[T], radr[T][2] + srcoff);
+            }
+            constexpr int NRD2 = KH > 2 ? PER : 0;
+            IFL_STAMP(2); // read issue + leading MFMAs (+ all reads landed, when stamping)
+            // ---- critical: taps (0,1) and (1,0) of r_{d-1} -> diagonal d -----------------------------------------
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (KW > 1) {
+                lgkm_wait_n((NDH - 1) * PER + NRD2); // the dh=0 fragments of all tiles have landed
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int T = 0; T < NTILE; ++T)
+                        if (MASK & (1 << T)) mf(T, 1, q, Fh[T][0][q], Fl[T][0][q], 0);
+            }
+            if constexpr (KH > 1) {
+                lgkm_wait_n(NRD2); // ... and the dh=1 fragments
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int T = 0; T < NTILE; ++T)
+                        if (MASK & (1 << T)) mf(T, KW, q, Fh[T][1][q], Fl[T][1][q], 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            IFL_STAMP(3); // critical MFMAs issued
+            // ---- epilogue (the chain): r_d = x + acc[0] -> split fp16 -> ring ---------------------------------
+#pragma unroll
+            for (int T = 0; T < NTILE; ++T)
+                if (MASK & (1 << T)) {
+                    const int w = w0 - 16 * T;
+                    const unsigned char *xp = xs + xadr[T] + qcur;
+                    float rv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        rv[r] = *(const float *)(xp + r * 16) + ahi[T][0][r] + amid[T][0][r] * LO_INV;
+                    if (hval[T] && (unsigned)w < (unsigned)W) {
+                        half4 hi, lo;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const _Float16 h16 = (_Float16)rv[r];
+                            hi[r] = h16;
+                            lo[r] = (_Float16)((rv[r] - (float)h16) * LO_SCALE);
+                        }
+                        *(half4 *)(ring + dstoff + wadr[T]) = hi;
+                        *(half4 *)(ring + dstoff + wadr[T] + 4 * 256) = lo;
+                        rmax = fmaxf(rmax, fmaxf(fmaxf(fabsf(rv[0]), fabsf(rv[1])), fmaxf(fabsf(rv[2]), fabsf(rv[3]))));
+                    }
+                    // rotate: diagonal d+1 becomes the head, a fresh accumulator joins for d+3
+                    ahi[T][0] = ahi[T][1];
+                    amid[T][0] = amid[T][1];
+                    ahi[T][1] = ahi[T][2];
+                    amid[T][1] = amid[T][2];
+                    ahi[T][2] = floatx4{0.f, 0.f, 0.f, 0.f};
+                    amid[T][2] = floatx4{0.f, 0.f, 0.f, 0.f};
                 }
-                mfma3(1, u, ch[u], cl2[u]);
-            }
             __builtin_amdgcn_sched_barrier(0);
+            IFL_STAMP(4); // epilogue
+            // ---- trailing: the remaining taps of r_{d-1} with dh < 2 (targets d+1, d+2) and z_{d-1} = L^-1 r_{d-1}
+#pragma unroll
+            for (int dh = 0; dh < NDH; ++dh)
+#pragma unroll
+                for (int dw = 0; dw < KW; ++dw)
+                    if (dh + dw >= 2) {
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                            for (int T = 0; T < NTILE; ++T)
+                                if (MASK & (1 << T))
+                                    mf(T, dh * KW + dw, q, Fh[T][dh][q], Fl[T][dh][q], dh + dw - 2);
+                    }
+            floatx4 zh[NTILE], zm[NTILE];
+#pragma unroll
+            for (int T = 0; T < NTILE; ++T)
+                if (MASK & (1 << T)) {
+                    zh[T] = floatx4{0.f, 0.f, 0.f, 0.f};
+                    zm[T] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        zh[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[NS - 1][q][0], Fh[T][0][q], zh[T], 0, 0, 0);
+                        zm[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[NS - 1][q][0], Fl[T][0][q], zm[T], 0, 0, 0);
+                        zm[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[NS - 1][q][1], Fh[T][0][q], zm[T], 0, 0, 0);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            IFL_STAMP(5); // trailing MFMAs issued
+            // z of diagonal d-1 -> staging, at the previous step's in-row offset (columns outside the image land in
+            // quads that are not live: before a row's first quad, or in the parity its last quad does not use)
+#pragma unroll
+            for (int T = 0; T < NTILE; ++T)
+                if (MASK & (1 << T)) {
+                    unsigned char *zp = zq + xadr[T] + qprev;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) *(float *)(zp + r * 16) = zh[T][r] + zm[T][r] * LO_INV;
+                }
         }
 
-        // ---- requests whose latency hides behind the MFMAs just issued: x of this step, the fragments of
-        //      the z product, the finished z quad(s) --------------------------------------------------------
-        float xv[4];
-        if constexpr (ACT) {
-            // this lane's 4 x values: quad (w>>2) of row h, channels c0..c0+3, element w&3
-            const unsigned char *xp = xs + xadr + ((w >> 2) & 1) * (C * 16) + (rw ? 3 - (w & 3) : (w & 3)) * 4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) xv[r] = *(const float *)(xp + r * 16);
-        }
-        const bool actz = d - 1 >= 16 * T && d - 1 <= 16 * T + 15 + W - 1 && d >= 1 && d <= ND && 16 * T < H;
-        half8 bh[NQ], bl[NQ];
-        if (actz) {
-            const unsigned char *pp = lds + soff[1] + radr[0];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                bh[q] = *(const half8 *)(pp + (q * 2) * 4 * 256);
-                bl[q] = *(const half8 *)(pp + (q * 2 + 1) * 4 * 256);
-            }
-        }
-        // store role: rows h = ph (mod 4) completed a quad of z with diagonal d-2; its four elements sit
-        // in the z-slots of diagonals d-5..d-2 (zoff[k] holds diagonal d-1-k)
-        floatx4 sv[G];
-        bool sok[G];
+        // ---- store role: rows h = ph (mod 4) completed a quad of z with diagonal d-2 (written one step ago) ----
         int nstore = 0;
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int hr = ph + 4 * (wave * G + i);
-            const int w3 = d - 2 - hr; // last column of the quad (w3 = 3 mod 4)
-            sok[i] = hr < H && w3 >= 3 && w3 < W; // wave-uniform
-            if (sok[i]) {
+            const int wq = d - 5 - hr; // first column of the quad
+            if (hr < H && (unsigned)wq < (unsigned)W) { // wave-uniform
                 nstore += 1;
-                const unsigned char *zp = zr + hr * Cfg::ZROWB + cl * 4;
-                sv[i][rw ? 3 : 0] = *(const float *)(zp + zoff[4]);
-                sv[i][rw ? 2 : 1] = *(const float *)(zp + zoff[3]);
-                sv[i][rw ? 1 : 2] = *(const float *)(zp + zoff[2]);
-                sv[i][rw ? 0 : 3] = *(const float *)(zp + zoff[1]);
-            }
-        }
-
-        // ---- (D) z of diagonal d-1 = L^-1 r: independent MFMAs that keep the matrix pipe busy while r_d is
-        //      converted and written ---------------------------------------------------------------------
-        floatx4 zh = {0.f, 0.f, 0.f, 0.f}, zm = {0.f, 0.f, 0.f, 0.f};
-        if (actz) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                zh = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[NS - 1][q][0], bh[q], zh, 0, 0, 0);
-                zm = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[NS - 1][q][0], bl[q], zm, 0, 0, 0);
-                zm = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[NS - 1][q][1], bh[q], zm, 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0); // MFMAs are in the pipe before the VALU-heavy tail starts
-#pragma unroll
-        for (int i = 0; i < G; ++i)
-            if (sok[i]) {
-                const int hr = ph + 4 * (wave * G + i);
-                const int w3 = d - 2 - hr;
-                const int hs = rh ? H - 1 - hr : hr;
-                const int ws = rw ? W - 1 - w3 : w3 - 3;
-                char *dstp = zg + ((size_t)hs * W + ws) * sizeof(float); // wave-uniform
+                const floatx4 sv = *(const floatx4 *)(zq + hr * Cfg::XROWB + ((wq >> 2) & 1) * (C * 16) + cl * 16);
+                char *dstp = zg + (gbase + hr * grow + wq * gcol); // wave-uniform
                 if (C == 64 || lane < C) {
-                    *(floatx4 *)(dstp + voff) = sv[i];
-                    zmax = fmaxf(zmax, fmaxf(fmaxf(fabsf(sv[i][0]), fabsf(sv[i][1])), fmaxf(fabsf(sv[i][2]), fabsf(sv[i][3]))));
+                    *(floatx4 *)(dstp + voff) = sv;
+                    zmax = fmaxf(zmax, fmaxf(fmaxf(fabsf(sv[0]), fabsf(sv[1])), fmaxf(fabsf(sv[2]), fabsf(sv[3]))));
                 }
             }
-
-        // ---- epilogue: r_d -> split fp16 -> ring; z_{d-1} -> z-ring ----------------------------------------
-        if constexpr (ACT) {
-            half4 hi, lo;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float rv = xv[r] + ahi[r] + amid[r] * LO_INV;
-                ovf |= (hval && w >= 0 && w < W) && !(fabsf(rv) < 6.0e4f);
-                const _Float16 h16 = (_Float16)rv;
-                hi[r] = h16;
-                lo[r] = (_Float16)((rv - (float)h16) * LO_SCALE);
-            }
-            if (hval && w >= 0 && w < W) {
-                *(half4 *)(ring + soff[0] + wadr) = hi;
-                *(half4 *)(ring + soff[0] + wadr + 4 * 256) = lo;
-            }
         }
-        if (actz) {
-            floatx4 zv;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) zv[r] = zh[r] + zm[r] * LO_INV;
-            *(floatx4 *)(zr + zoff[0] + zadr) = zv; // lanes outside the image write values nobody stores
-        }
-
-        // rotate the slot tables: diagonal d+1 takes the slot of diagonal d-(R-1), likewise for z
-        {
-            const int last = soff[R - 1];
-#pragma unroll
-            for (int k = R - 1; k > 0; --k) soff[k] = soff[k - 1];
-            soff[0] = last;
-            const int zlast = zoff[RZ - 1];
-#pragma unroll
-            for (int k = RZ - 1; k > 0; --k) zoff[k] = zoff[k - 1];
-            zoff[0] = zlast;
-        }
+        qprev = qcur;
         nst[2] = nst[1];
         nst[1] = nst[0];
         nst[0] = nstore;
+        IFL_STAMP(6); // z stores
     };
 
-    for (int d = -3; d <= ND + 1; ++d) {
-        // wave-uniform: does this wave's tile hold any pixel of diagonal d?
-        const bool act = d >= 16 * T && d <= 16 * T + 15 + W - 1 && d < ND && 16 * T < H;
-        if (act)
-            step(std::true_type{}, d);
-        else
-            step(std::false_type{}, d);
+    // A tile's window runs from two steps before its first pixel (the dh=2 fragments and the early pushes) to
+    // the step after its last one (the z product of the last diagonal): the sets of active tiles come in the
+    // order {}, {0}, {0,1}, {1}, {} -- one loop per set, so that no control flow merges inside a step.
+    {
+        const int last0 = (15 + W - 1 < ND - 1 ? 15 + W - 1 : ND - 1) + 1; // last step of tile 0
+        const int first1 = NTILE == 2 ? 14 : ND + 2;                       // first step of tile 1
+        int d = -3;
+        for (; d < -2; ++d) step(std::integral_constant<int, 0>{}, d);
+        for (; d <= last0 && d < first1; ++d) step(std::integral_constant<int, 1>{}, d);
+        if constexpr (NTILE == 2) {
+            for (; d <= last0; ++d) step(std::integral_constant<int, 3>{}, d);
+            for (; d <= ND; ++d) step(std::integral_constant<int, 2>{}, d);
+        }
+        for (; d <= ND + 1; ++d) step(std::integral_constant<int, 0>{}, d);
     }
+
+#ifdef IFL_STAMPS
+    if (g_stamps && b == 0 && lane == 0)
+        for (int k = 0; k < 8; ++k) g_stamps[wave * 8 + k] = st_acc[k];
+#endif
     // Split fp16 cannot hold |r| >= 65504 (a badly conditioned operator grows r along the sweep): such an
     // image is redone here, by the same workgroup, in exact fp32 from the fp32 copy of the same folded
     // weights (general scan body, right-fold form).  Rare, slow, but never a silent Inf/NaN where the exact
     // solver is finite.  flags[] records it for the caller (diagnostics only).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no LDS-DMA may still be landing in the LDS reused below
-    const int redo = __syncthreads_or(ovf ? 1 : 0);
+    const int redo = __syncthreads_or(rmax < 6.0e4f ? 0 : 1);
     if (tid == 0) flags[b] = redo ? 1 : 0; // every workgroup owns its word: no clearing pass needed
     if (redo) {
         scan_general_body<Cfg::THREADS>(xin, wf32, zout, geom, rh, rw, 1, (float *)lds, b, tid);
@@ -655,6 +679,12 @@ static int launch_one(const float *x, float *z, const void *apack, const Geom &g
     }
     if (scan_general_lds_bytes(g) > (size_t)Cfg::LDSB)
         IFL_FAIL(IFL_EUNSUPPORTED, "launch_scan_mfma: fp32 fallback does not fit the kernel's LDS");
+#ifdef IFL_STAMPS
+    if (const char *e = getenv("IFL_STAMPS")) {
+        unsigned long long *ptr = (unsigned long long *)strtoull(e, nullptr, 0);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &ptr, sizeof(ptr));
+    }
+#endif
     hipLaunchKernelGGL((k_scan_mfma<C, KH, KW, NTILE>), dim3(g.B), dim3(Cfg::THREADS), Cfg::LDSB, s, x, z,
                        (const half8 *)apack, g.H, g.W, rh, rw, flags, wf32, g, amax);
     IFL_HIP(hipGetLastError());

@@ -1,8 +1,13 @@
+"""Per-section cycle counts of the MFMA scan's step (development aid).
+
+Build the library with the stamps compiled in, run on the GPU box, then rebuild without:
+    HIPCC_EXTRA=-DIFL_STAMPS python inverse-flow_amd/build.py --force && python tools/stamps.py
+"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "inverse-flow_amd")); sys.path.insert(0, ROOT)
 import torch
-buf = torch.zeros(8 * 2 * 8, dtype=torch.int64, device="cuda")
+buf = torch.zeros(8 * 8, dtype=torch.int64, device="cuda")
 os.environ["IFL_STAMPS"] = str(buf.data_ptr())
 import invflow_hip as H
 from bench import ref_init_weight, B, C, HH, WW
@@ -12,10 +17,10 @@ x = torch.randn(B, C, HH, WW, device="cuda"); z = torch.empty_like(x)
 for _ in range(3):
     H.inverse(x, w, out=z)
 torch.cuda.synchronize()
-t = buf.cpu().view(8, 2, 8)
-names = ["dma", "B", "wait+bar", "C", "reads", "D+store", "epilogue", "iters"]
+t = buf.cpu().view(8, 8)
+names = ["dma", "wait+bar", "reads+lead", "crit", "epilogue", "trail", "stores", "loop"]
 for wv in range(8):
-    for a in range(2):
-        r = t[wv, a].tolist()
-        n = max(r[7], 1)
-        print("wave", wv, "act" if a else "idle", {names[k]: round(r[k] / n) for k in range(7)}, "iters", r[7], "total", sum(r[:7]))
+    r = t[wv].tolist()
+    if sum(r) == 0:
+        continue
+    print("wave", wv, {names[k]: r[k] for k in range(8)}, "total", sum(r))

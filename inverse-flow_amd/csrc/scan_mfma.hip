@@ -62,8 +62,8 @@ template <int C, int KH, int KW, int NTILE> struct ScanCfg {
     static constexpr int RINGB = R * SLOTB;
     static constexpr int XROWB = 2 * C * 16 + 16; // quads of one row: [parity][channel][4] + pad (x staging and z staging)
     static constexpr int XSB = 16 * NTILE * XROWB;
-    static constexpr int OFF_XS = RINGB, OFF_ZQ = OFF_XS + XSB;
-    static constexpr int LDSB = OFF_ZQ + XSB;
+    static constexpr int OFF_XS = RINGB, OFF_ZQ = OFF_XS + XSB, OFF_DUMP = OFF_ZQ + XSB;
+    static constexpr int LDSB = OFF_DUMP + 4 * 256 + 64 * NWAVES * 8; // dump: where lanes outside the image write their r (branch-free epilogue)
     static constexpr int THREADS = 64 * NWAVES;
     static constexpr int ROWS_PER_ITER = 4 * NTILE; // rows that start/finish a quad each step
     static constexpr int G = ROWS_PER_ITER / NWAVES; // ... per wave: DMA (and at most as many store) instructions
@@ -96,6 +96,17 @@ template <int NQ, int OFF> __device__ __forceinline__ void lds_read_set(half8 (&
         lds_read_b128_o<OFF + 12 * 256>(l[1], addr);
     }
 }
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef float floatx4_ __attribute__((ext_vector_type(4)));
+// two floats 16 B apart (elements r, r+1 of a staged quad group) / one staged quad
+template <int DW0> __device__ __forceinline__ void lds_read2_f32(floatx2 &v, unsigned addr)
+{
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(DW0), "n"(DW0 + 4));
+}
+__device__ __forceinline__ void lds_read_f32x4(floatx4_ &v, unsigned addr)
+{
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+}
 template <int N> __device__ __forceinline__ void lgkm_wait(half8 &a, half8 &b)
 {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
@@ -114,16 +125,14 @@ __device__ __forceinline__ void lgkm_wait_n(int n)
     __builtin_amdgcn_sched_barrier(0); // nothing that consumes the data may be scheduled above the wait
 }
 
-// "all but the n youngest vector-memory operations of this wave are complete", LDS drained, then the
-// workgroup barrier.  n is exact (see the step body) and wave-uniform.
-__device__ __forceinline__ void wait_vm_then_barrier(int n)
+// "all but the BASE+k youngest vector-memory operations of this wave are complete", LDS drained, then the
+// workgroup barrier.  The count is exact (see the step body) and wave-uniform; k = 0..8.
+template <int BASE> __device__ __forceinline__ void wait_vm_then_barrier(int k)
 {
-#define IFL_W(N) \
-    case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-    switch (__builtin_amdgcn_readfirstlane(n)) {
-        IFL_W(0) IFL_W(1) IFL_W(2) IFL_W(3) IFL_W(4) IFL_W(5) IFL_W(6) IFL_W(7) IFL_W(8) IFL_W(9) IFL_W(10) IFL_W(11)
-        IFL_W(12) IFL_W(13) IFL_W(14) IFL_W(15) IFL_W(16) IFL_W(17) IFL_W(18) IFL_W(19) IFL_W(20) IFL_W(21) IFL_W(22)
-        IFL_W(23) IFL_W(24)
+#define IFL_W(K) \
+    case K: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(BASE + K) : "memory"); break;
+    switch (__builtin_amdgcn_readfirstlane(k)) {
+        IFL_W(0) IFL_W(1) IFL_W(2) IFL_W(3) IFL_W(4) IFL_W(5) IFL_W(6) IFL_W(7) IFL_W(8)
     default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
     }
 #undef IFL_W
@@ -216,10 +225,19 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
     const int grow = rh ? -4 * W : 4 * W, gcol = rw ? -4 : 4;
     const int gbase = (rh ? (H - 1) * 4 * W : 0) + (rw ? (W - 4) * 4 : 0);
 
-    int nst[3] = {0, 0, 0}; // store instructions this wave issued in the previous three steps
+    int nst[2] = {0, 0};    // store instructions this wave issued in the previous two steps
     float rmax = 0.f;       // max |r| this lane put into the ring: beyond the fp16 range the image is redone in fp32
     float zmax = 0.f;       // max |z| this lane stored (handed to the weight-gradient kernel as its prescale)
-    int qprev = 0;          // in-row staging offset (parity, position in the quad) of the previous step's column
+    int qprev = 0, qprev2 = 0; // in-row staging offsets (parity, position in the quad) of the two previous steps' columns
+    floatx4 zh[NTILE], zm[NTILE]; // z product of the previous step, written to the staging area during this one
+#pragma unroll
+    for (int T = 0; T < NTILE; ++T) {
+        zh[T] = floatx4{0.f, 0.f, 0.f, 0.f};
+        zm[T] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    // kernel arguments used in the loop, held in scalar registers (a reload would wait on the LDS counter)
+    int Hs = H, Ws = W;
+    asm volatile("" : "+s"(Hs), "+s"(Ws));
 
     // Rolling accumulators ("push" form): acc[k] collects everything the taps contribute to diagonal d+k; the
     // step that finishes diagonal d only adds the two taps whose source is r_{d-1}.
@@ -248,127 +266,266 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
 #endif
     __syncthreads();
 
-    // One step, specialised on the set of tiles in their active window.  Source diagonal d-1 is read from LDS
+    // One step, specialised on the tiles in their active window (MASK) and on those that were active in the
+    // previous step (PMASK: their z product is still to be written out).  Source diagonal d-1 is read from LDS
     // ONCE (three row-shifted fragment sets per tile); each tap pushes it into the accumulator of the diagonal
     // it lands on:
     //   leading  : the dh=2 taps of r_{d-2} (fragments kept in registers from the previous step) -- they fill
     //              the matrix pipe while this step's fragment reads are in flight,
-    //   critical : the two taps whose target is diagonal d itself, then r_d = x + acc -> ring  (the chain),
-    //   trailing : the other taps of r_{d-1} and the z product, behind the epilogue.
-    // The scan is bound by instruction issue (one wave per SIMD), so everything around the MFMAs is kept short:
-    // 32-bit scalar address arithmetic, one staging layout for x and z, no per-element selects.
-    auto step = [&](auto mask_c, const int d) {
-        constexpr int MASK = decltype(mask_c)::value;
+    //   critical : the two taps whose target is diagonal d itself,
+    //   trailing : the other taps of r_{d-1} and the z product.
+    // One wave per SIMD: nothing overlaps unless the instruction stream interleaves it.  Everything that is not
+    // on the chain is therefore cut into chunks that sit between MFMA groups (an MFMA occupies the matrix pipe
+    // for 16 cycles, the wave issues ~3 other instructions meanwhile):
+    //   leading  <- z of the previous step -> staging, completed z quads -> global (store role)
+    //   critical <- address arithmetic + issue of the x quads needed three steps from now (DMA role)
+    //   trailing <- the chain's epilogue r_d = x + acc -> split fp16 -> ring
+    auto step = [&](auto mask_c, auto pmask_c, const int d) {
+        constexpr int MASK = decltype(mask_c)::value, PMASK = decltype(pmask_c)::value;
         constexpr int NA = (MASK & 1) + ((MASK >> 1) & 1);
+        constexpr int NDH = KH < 2 ? KH : 2;
+        constexpr int PER = NA * NQ * 2; // reads per fragment set
+        constexpr int NRD2 = (KH > 2 && MASK != 0) ? PER : 0;
         const int srcoff = ((d + 1) & 1) * SLOTB; // ring slot of diagonal d-1 (slot = diagonal mod 2)
         const int dstoff = (d & 1) * SLOTB;       // ring slot of diagonal d
-        const int ph = (d - 1) & 3;               // rows h = ph (mod 4) are one step into a quad of x
         IFL_STAMP(7); // loop control
 
-        // ---- x quads needed three steps from now (unconditional: exact VM operation count) ----------------
-#pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const int hr = ph + 4 * (wave * G + i);
-            const int wq = d - hr + 3;
-            const bool ok = hr < H && (unsigned)wq < (unsigned)W;
-            const int off = ok ? gbase + hr * grow + wq * gcol : 0;
-            const char *src = xg + off; // wave-uniform
-            unsigned char *dst = xs + hr * Cfg::XROWB + ((wq >> 2) & 1) * (C * 16); // lane c lands at +16c
-            if (C == 64 || lane < C)
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + voff),
-                                                 (void __attribute__((address_space(3))) *)dst, 16, 0, 0);
-        }
-
-        // The quads this wave DMA'd three steps ago must have landed before anyone reads them below:
-        // younger than those are exactly the stores of steps d-3..d-1 and the DMAs of steps d-2..d.
-        // Then the barrier: r of diagonal d-1 (and z of diagonal d-2) are complete in LDS.
-        IFL_STAMP(0); // DMA issue
-        wait_vm_then_barrier(3 * G + nst[0] + nst[1] + nst[2]);
+        // The quads this wave DMA'd three steps ago must have landed before anyone reads them below: younger
+        // than those are exactly the stores and DMAs of steps d-2 and d-1 (a step issues its stores first).
+        // Then the barrier: r of diagonal d-1 and the z staged in step d-1 are complete in LDS.
+        wait_vm_then_barrier<2 * G>(nst[0] + nst[1]);
         IFL_STAMP(1); // wait + barrier
-
-        auto mf = [&](int T, int t, int q, const half8 &vh, const half8 &vl, int tgt) {
-            ahi[T][tgt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], vh, ahi[T][tgt], 0, 0, 0);
-            amid[T][tgt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], vl, amid[T][tgt], 0, 0, 0);
-            amid[T][tgt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][1], vh, amid[T][tgt], 0, 0, 0);
-        };
 
         // in-row staging offset of this step's column w = d - h: the same for all tiles (rows 16 apart)
         const int w0 = d - n;
         const int qcur = ((w0 >> 2) & 1) * (C * 16) + (rw ? 3 - (w0 & 3) : (w0 & 3)) * 4;
 
-        if constexpr (MASK != 0) {
-            // ---- requests: fragments of r_{d-1} for the rows 0 and 1 up, row-major so that the dh=0 sets of all
-            //      tiles land first (the dh=2 sets follow the leading MFMAs)
-            half8 Fh[NTILE][2][NQ], Fl[NTILE][2][NQ];
-            constexpr int NDH = KH < 2 ? KH : 2;
+        // ---- LDS requests, oldest first: staged z quads (store role), x of this step, fragments.  They are
+        //      numbered so that they can be issued a few at a time between the first leading MFMAs. ----------------
+        // store role: rows h = d-2 (mod 4) completed a quad of z with diagonal d-3 (staged one step ago)
+        const int ps = (d - 2) & 3;
+        floatx4_ sv[G];
+        floatx2 xq[NTILE][2];
+        half8 Fh[NTILE][2][NQ], Fl[NTILE][2][NQ];
+        constexpr int NREQ = G + (MASK != 0 ? 2 * NA + NDH * PER : 0);
+        auto request = [&](int j) {
+            int c = 0;
 #pragma unroll
-            for (int dh = 0; dh < NDH; ++dh)
+            for (int i = 0; i < G; ++i)
+                if (c++ == j) {
+                    const int hr = ps + 4 * (wave + Cfg::NWAVES * i);
+                    const int wq = d - 6 - hr; // first column of the quad (any value: the read stays inside the staging area)
+                    lds_read_f32x4(sv[i], ldsbase + Cfg::OFF_ZQ + hr * Cfg::XROWB + ((wq >> 2) & 1) * (C * 16) + cl * 16);
+                }
+            if constexpr (MASK != 0) {
 #pragma unroll
                 for (int T = 0; T < NTILE; ++T)
-                    if (MASK & (1 << T)) lds_read_set<NQ, 0>(Fh[T][dh], Fl[T][dh], radr[T][dh] + srcoff);
-            constexpr int PER = NA * NQ * 2; // reads per dh set
+                    if (MASK & (1 << T)) {
+                        const unsigned xa = ldsbase + Cfg::OFF_XS + xadr[T] + qcur;
+                        if (c++ == j) lds_read2_f32<0>(xq[T][0], xa);
+                        if (c++ == j) lds_read2_f32<8>(xq[T][1], xa);
+                    }
+#pragma unroll
+                for (int dh = 0; dh < NDH; ++dh)
+#pragma unroll
+                    for (int T = 0; T < NTILE; ++T)
+                        if (MASK & (1 << T)) {
+                            const unsigned fa = radr[T][dh] + srcoff;
+                            if (c++ == j) lds_read_b128_o<0>(Fh[T][dh][0], fa);
+                            if (c++ == j) lds_read_b128_o<4 * 256>(Fl[T][dh][0], fa);
+                            if constexpr (NQ == 2) {
+                                if (c++ == j) lds_read_b128_o<8 * 256>(Fh[T][dh][1], fa);
+                                if (c++ == j) lds_read_b128_o<12 * 256>(Fl[T][dh][1], fa);
+                            }
+                        }
+            }
+        };
+        constexpr int NYOUNG = (MASK != 0 ? 2 * NA + NDH * PER : 0); // LDS requests younger than the staged quads
+        __builtin_amdgcn_sched_barrier(0);
+
+        // A(t) x {hi, lo} fragments of all active tiles -> accumulator tgt; dependent MFMAs kept apart
+        // order: per k-step the hi.hi and hi.lo products of all tiles, then the lo.hi products
+        auto mf_one = [&](int t, const auto &fh, const auto &fl, int dh, int tgt, int k) {
+            int c = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+                for (int T = 0; T < NTILE; ++T)
+                    if (MASK & (1 << T))
+                        if (c++ == k)
+                            ahi[T][tgt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], fh(T, dh, q), ahi[T][tgt], 0, 0, 0);
+#pragma unroll
+                for (int T = 0; T < NTILE; ++T)
+                    if (MASK & (1 << T))
+                        if (c++ == k)
+                            amid[T][tgt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], fl(T, dh, q), amid[T][tgt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int T = 0; T < NTILE; ++T)
+                    if (MASK & (1 << T))
+                        if (c++ == k)
+                            amid[T][tgt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][1], fh(T, dh, q), amid[T][tgt], 0, 0, 0);
+        };
+        auto mf = [&](int t, const auto &fh, const auto &fl, int dh, int tgt) {
+#pragma unroll
+            for (int k = 0; k < 3 * NQ * NA; ++k) mf_one(t, fh, fl, dh, tgt, k);
+        };
+        auto fence = [&]() { __builtin_amdgcn_sched_barrier(0); };
+        // scheduling pattern for the region since the last fence: `lead` MFMAs, then NM x (1 MFMA, NV others)
+        auto weave = [&](auto lead_c, auto nm_c, auto nv_c) {
+            constexpr int LEAD = decltype(lead_c)::value, NM = decltype(nm_c)::value, NV = decltype(nv_c)::value;
+            if constexpr (LEAD > 0) __builtin_amdgcn_sched_group_barrier(0x008, LEAD, 0);
+#pragma unroll
+            for (int k = 0; k < NM; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x296, NV, 0); // VALU | SALU | VMEM | DS
+            }
             __builtin_amdgcn_sched_barrier(0);
+        };
+        auto f2h = [&](int T, int, int q) -> const half8 & { return F2h[T][q]; };
+        auto f2l = [&](int T, int, int q) -> const half8 & { return F2l[T][q]; };
+        auto f1h = [&](int T, int dh, int q) -> const half8 & { return Fh[T][dh][q]; };
+        auto f1l = [&](int T, int dh, int q) -> const half8 & { return Fl[T][dh][q]; };
+
+        // ---- chunk: z of diagonal d-2 (computed one step ago) -> staging, at that column's in-row offset
+        //      (columns outside the image land in quads that are not live: before a row's first quad, or in the
+        //      parity its last quad does not use) -----------------------------------------------------------
+        auto chunk_zstage = [&]() {
+#pragma unroll
+            for (int T = 0; T < NTILE; ++T)
+                if (PMASK & (1 << T)) {
+                    unsigned char *zp = zq + xadr[T] + qprev2;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) *(float *)(zp + r * 16) = zh[T][r] + zm[T][r] * LO_INV;
+                }
+        };
+        // ---- chunk: store role ----------------------------------------------------------------------------
+        int nstore = 0;
+        auto chunk_store = [&]() {
+            lgkm_wait_n(NYOUNG); // the staged quads have landed (they are the oldest requests)
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int hr = ps + 4 * (wave + Cfg::NWAVES * i);
+                const int wq = d - 6 - hr;
+                if (hr < Hs && (unsigned)wq < (unsigned)Ws) { // wave-uniform
+                    nstore += 1;
+                    char *dstp = zg + (gbase + hr * grow + wq * gcol); // wave-uniform
+                    if (C == 64 || lane < C) {
+                        *(floatx4_ *)(dstp + voff) = sv[i];
+                        zmax = fmaxf(zmax, fmaxf(fmaxf(fabsf(sv[i][0]), fabsf(sv[i][1])), fmaxf(fabsf(sv[i][2]), fabsf(sv[i][3]))));
+                    }
+                }
+            }
+        };
+        // ---- chunk: DMA role, x quads needed three steps from now (unconditional: exact VM operation count) -
+        auto chunk_dma = [&](int i) {
+            const int hr = ((d - 1) & 3) + 4 * (wave + Cfg::NWAVES * i); // rows h = d-1 (mod 4) are one step into a quad of x
+            const int wq = d - hr + 3;
+            const int okm = (hr < Hs && (unsigned)wq < (unsigned)Ws) ? -1 : 0;
+            const int off = (gbase + hr * grow + wq * gcol) & okm;
+            const char *src = xg + off; // wave-uniform
+            unsigned char *dst = xs + hr * Cfg::XROWB + ((wq >> 2) & 1) * (C * 16); // lane c lands at +16c
+            if (C == 64 || lane < C)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + voff),
+                                                 (void __attribute__((address_space(3))) *)dst, 16, 0, 0);
+        };
+        // ---- chunk: epilogue of tile T (the chain): r_d = x + acc[0] -> split fp16 -> ring; then the accumulators
+        //      rotate: diagonal d+1 becomes the head, a fresh one joins for d+3 -------------------------------
+        auto chunk_epilogue = [&](int T) {
+            const int w = w0 - 16 * T;
+            const bool valid = hval[T] && (unsigned)w < (unsigned)Ws;
+            float rv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rv[r] = xq[T][r >> 1][r & 1] + ahi[T][0][r] + amid[T][0][r] * LO_INV;
+            half4 hi, lo;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const _Float16 h16 = (_Float16)rv[r];
+                hi[r] = h16;
+                lo[r] = (_Float16)((rv[r] - (float)h16) * LO_SCALE);
+            }
+            // lanes outside the image write to the dump (no branch: the MFMAs around this chunk keep flowing)
+            unsigned char *rp = valid ? ring + dstoff + wadr[T] : lds + Cfg::OFF_DUMP + tid * 8;
+            *(half4 *)rp = hi;
+            *(half4 *)(rp + 4 * 256) = lo;
+            const float m = fmaxf(fmaxf(fabsf(rv[0]), fabsf(rv[1])), fmaxf(fabsf(rv[2]), fabsf(rv[3])));
+            rmax = valid ? fmaxf(rmax, m) : rmax;
+        };
+
+        using N0 = std::integral_constant<int, 0>;
+        constexpr int GM = 3 * NQ * NA; // MFMAs of one tap group
+        using NGM = std::integral_constant<int, GM>;
+        if constexpr (MASK == 0) {
+#pragma unroll
+            for (int j = 0; j < NREQ; ++j) request(j);
+            fence();
+            chunk_zstage();
+            chunk_store();
+#pragma unroll
+            for (int i = 0; i < G; ++i) chunk_dma(i);
+            fence();
+        } else {
             // ---- leading: taps (2, dw) of r_{d-2}; their targets are diagonals d-2+2+dw = d + dw -----------
             if constexpr (KH > 2) {
+                // the first group carries the LDS requests (inline asm: placed by hand, two behind each MFMA)
+                constexpr int RPM = (NREQ + GM - 1) / GM;
 #pragma unroll
-                for (int dw = 0; dw < KW; ++dw)
+                for (int k = 0; k < GM; ++k) {
+                    mf_one(2 * KW + 0, f2h, f2l, 0, 0, k);
+                    fence();
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q)
+                    for (int j = k * RPM; j < (k + 1) * RPM && j < NREQ; ++j) request(j);
+                    fence();
+                }
+                if constexpr (KW > 1) mf(2 * KW + 1, f2h, f2l, 0, 1);
+                chunk_zstage();
+                weave(N0{}, NGM{}, std::integral_constant<int, 3>{});
+                chunk_store();
+                fence();
+                if constexpr (KW > 2) mf(2 * KW + 2, f2h, f2l, 0, 2);
 #pragma unroll
-                        for (int T = 0; T < NTILE; ++T)
-                            if (MASK & (1 << T)) mf(T, 2 * KW + dw, q, F2h[T][q], F2l[T][q], dw);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < G; ++i) chunk_dma(i);
+                weave(N0{}, NGM{}, std::integral_constant<int, 4>{});
                 asm volatile("s_nop 7" ::: "memory"); // margin between the last operand read and the reload below
                 // this step's dh=2 fragments of r_{d-1}, for the next step's leading MFMAs
 #pragma unroll
                 for (int T = 0; T < NTILE; ++T)
                     if (MASK & (1 << T)) lds_read_set<NQ, 0>(F2h[T], F2l[T], radr[T][2] + srcoff);
+                fence();
+            } else {
+#pragma unroll
+                for (int j = 0; j < NREQ; ++j) request(j);
+                fence();
+                chunk_zstage();
+                chunk_store();
+#pragma unroll
+                for (int i = 0; i < G; ++i) chunk_dma(i);
+                fence();
             }
-            constexpr int NRD2 = KH > 2 ? PER : 0;
             IFL_STAMP(2); // read issue + leading MFMAs (+ all reads landed, when stamping)
             // ---- critical: taps (0,1) and (1,0) of r_{d-1} -> diagonal d -----------------------------------------
-            __builtin_amdgcn_sched_barrier(0);
             if constexpr (KW > 1) {
                 lgkm_wait_n((NDH - 1) * PER + NRD2); // the dh=0 fragments of all tiles have landed
-#pragma unroll
-                for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                    for (int T = 0; T < NTILE; ++T)
-                        if (MASK & (1 << T)) mf(T, 1, q, Fh[T][0][q], Fl[T][0][q], 0);
+                mf(1, f1h, f1l, 0, 0);
+                fence();
             }
             if constexpr (KH > 1) {
                 lgkm_wait_n(NRD2); // ... and the dh=1 fragments
-#pragma unroll
-                for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                    for (int T = 0; T < NTILE; ++T)
-                        if (MASK & (1 << T)) mf(T, KW, q, Fh[T][1][q], Fl[T][1][q], 0);
+                mf(KW, f1h, f1l, 1, 0);
+                fence();
             }
-            __builtin_amdgcn_sched_barrier(0);
             IFL_STAMP(3); // critical MFMAs issued
-            // ---- epilogue (the chain): r_d = x + acc[0] -> split fp16 -> ring ---------------------------------
+            // ---- trailing: the remaining taps of r_{d-1} with dh < 2 (targets d+1, d+2) and z_{d-1} = L^-1 r_{d-1},
+            //      the epilogue of the chain woven into the first groups.  The accumulators rotate first (diagonal
+            //      d+1 becomes the head, a fresh one joins for d+3); the epilogue works on the old head.
+            floatx4 head_hi[NTILE], head_mid[NTILE];
 #pragma unroll
             for (int T = 0; T < NTILE; ++T)
                 if (MASK & (1 << T)) {
-                    const int w = w0 - 16 * T;
-                    const unsigned char *xp = xs + xadr[T] + qcur;
-                    float rv[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        rv[r] = *(const float *)(xp + r * 16) + ahi[T][0][r] + amid[T][0][r] * LO_INV;
-                    if (hval[T] && (unsigned)w < (unsigned)W) {
-                        half4 hi, lo;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const _Float16 h16 = (_Float16)rv[r];
-                            hi[r] = h16;
-                            lo[r] = (_Float16)((rv[r] - (float)h16) * LO_SCALE);
-                        }
-                        *(half4 *)(ring + dstoff + wadr[T]) = hi;
-                        *(half4 *)(ring + dstoff + wadr[T] + 4 * 256) = lo;
-                        rmax = fmaxf(rmax, fmaxf(fmaxf(fabsf(rv[0]), fabsf(rv[1])), fmaxf(fabsf(rv[2]), fabsf(rv[3]))));
-                    }
-                    // rotate: diagonal d+1 becomes the head, a fresh accumulator joins for d+3
+                    head_hi[T] = ahi[T][0];
+                    head_mid[T] = amid[T][0];
                     ahi[T][0] = ahi[T][1];
                     amid[T][0] = amid[T][1];
                     ahi[T][1] = ahi[T][2];
@@ -376,84 +533,97 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
                     ahi[T][2] = floatx4{0.f, 0.f, 0.f, 0.f};
                     amid[T][2] = floatx4{0.f, 0.f, 0.f, 0.f};
                 }
-            __builtin_amdgcn_sched_barrier(0);
-            IFL_STAMP(4); // epilogue
-            // ---- trailing: the remaining taps of r_{d-1} with dh < 2 (targets d+1, d+2) and z_{d-1} = L^-1 r_{d-1}
+            auto epi = [&](int T) {
+                if (MASK & (1 << T)) {
+                    const floatx4 sh = ahi[T][0], sm = amid[T][0]; // keep the rotated values out of the chunk's way
+                    ahi[T][0] = head_hi[T];
+                    amid[T][0] = head_mid[T];
+                    chunk_epilogue(T);
+                    ahi[T][0] = sh;
+                    amid[T][0] = sm;
+                }
+            };
+            int ntr = 0; // trailing groups issued so far: the epilogues ride on the first and the second
+            auto after_group = [&]() {
+                constexpr int LEADM = GM < 4 ? GM : 4; // the head's last MFMA needs a few issue slots to finish
+                if (ntr == 0) {
+                    epi(0);
+                    weave(std::integral_constant<int, LEADM>{}, std::integral_constant<int, GM - LEADM>{},
+                          std::integral_constant<int, 5>{});
+                } else if (ntr == 1 && NTILE > 1) {
+                    epi(1);
+                    weave(N0{}, NGM{}, std::integral_constant<int, 4>{});
+                } else {
+                    fence();
+                }
+                ++ntr;
+            };
 #pragma unroll
             for (int dh = 0; dh < NDH; ++dh)
 #pragma unroll
                 for (int dw = 0; dw < KW; ++dw)
                     if (dh + dw >= 2) {
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                            for (int T = 0; T < NTILE; ++T)
-                                if (MASK & (1 << T))
-                                    mf(T, dh * KW + dw, q, Fh[T][dh][q], Fl[T][dh][q], dh + dw - 2);
+                        mf(dh * KW + dw, f1h, f1l, dh, dh + dw - 2);
+                        after_group();
                     }
-            floatx4 zh[NTILE], zm[NTILE];
+            // z product (its own accumulators, carried to the next step's staging chunk)
 #pragma unroll
-            for (int T = 0; T < NTILE; ++T)
-                if (MASK & (1 << T)) {
-                    zh[T] = floatx4{0.f, 0.f, 0.f, 0.f};
-                    zm[T] = floatx4{0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        zh[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[NS - 1][q][0], Fh[T][0][q], zh[T], 0, 0, 0);
-                        zm[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[NS - 1][q][0], Fl[T][0][q], zm[T], 0, 0, 0);
+                for (int T = 0; T < NTILE; ++T)
+                    if (MASK & (1 << T)) {
+                        const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+                        zh[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[NS - 1][q][0], Fh[T][0][q], q ? zh[T] : zero, 0, 0, 0);
+                    }
+#pragma unroll
+                for (int T = 0; T < NTILE; ++T)
+                    if (MASK & (1 << T)) {
+                        const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+                        zm[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[NS - 1][q][0], Fl[T][0][q], q ? zm[T] : zero, 0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int T = 0; T < NTILE; ++T)
+                    if (MASK & (1 << T))
                         zm[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[NS - 1][q][1], Fh[T][0][q], zm[T], 0, 0, 0);
-                    }
-                }
-            __builtin_amdgcn_sched_barrier(0);
+            after_group();
             IFL_STAMP(5); // trailing MFMAs issued
-            // z of diagonal d-1 -> staging, at the previous step's in-row offset (columns outside the image land in
-            // quads that are not live: before a row's first quad, or in the parity its last quad does not use)
-#pragma unroll
-            for (int T = 0; T < NTILE; ++T)
-                if (MASK & (1 << T)) {
-                    unsigned char *zp = zq + xadr[T] + qprev;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) *(float *)(zp + r * 16) = zh[T][r] + zm[T][r] * LO_INV;
-                }
         }
 
-        // ---- store role: rows h = ph (mod 4) completed a quad of z with diagonal d-2 (written one step ago) ----
-        int nstore = 0;
-#pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const int hr = ph + 4 * (wave * G + i);
-            const int wq = d - 5 - hr; // first column of the quad
-            if (hr < H && (unsigned)wq < (unsigned)W) { // wave-uniform
-                nstore += 1;
-                const floatx4 sv = *(const floatx4 *)(zq + hr * Cfg::XROWB + ((wq >> 2) & 1) * (C * 16) + cl * 16);
-                char *dstp = zg + (gbase + hr * grow + wq * gcol); // wave-uniform
-                if (C == 64 || lane < C) {
-                    *(floatx4 *)(dstp + voff) = sv;
-                    zmax = fmaxf(zmax, fmaxf(fmaxf(fabsf(sv[0]), fabsf(sv[1])), fmaxf(fabsf(sv[2]), fabsf(sv[3]))));
-                }
-            }
-        }
+        qprev2 = qprev;
         qprev = qcur;
-        nst[2] = nst[1];
         nst[1] = nst[0];
         nst[0] = nstore;
-        IFL_STAMP(6); // z stores
+        IFL_STAMP(6); // bookkeeping
     };
 
     // A tile's window runs from two steps before its first pixel (the dh=2 fragments and the early pushes) to
     // the step after its last one (the z product of the last diagonal): the sets of active tiles come in the
-    // order {}, {0}, {0,1}, {1}, {} -- one loop per set, so that no control flow merges inside a step.
+    // order {}, {0}, {0,1}, {1}, {} -- one loop per set (its first step peeled: the previous set's z products
+    // are still to be staged), so that no control flow merges inside a step.  Two more steps drain the staging.
     {
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
         const int last0 = (15 + W - 1 < ND - 1 ? 15 + W - 1 : ND - 1) + 1; // last step of tile 0
-        const int first1 = NTILE == 2 ? 14 : ND + 2;                       // first step of tile 1
         int d = -3;
-        for (; d < -2; ++d) step(std::integral_constant<int, 0>{}, d);
-        for (; d <= last0 && d < first1; ++d) step(std::integral_constant<int, 1>{}, d);
+        step(I0{}, I0{}, d++);
+        step(I1{}, I0{}, d++);
         if constexpr (NTILE == 2) {
-            for (; d <= last0; ++d) step(std::integral_constant<int, 3>{}, d);
-            for (; d <= ND; ++d) step(std::integral_constant<int, 2>{}, d);
+            using I2 = std::integral_constant<int, 2>;
+            using I3 = std::integral_constant<int, 3>;
+            for (; d < 14; ++d) step(I1{}, I1{}, d);
+            step(I3{}, I1{}, d++);
+            for (; d <= last0; ++d) step(I3{}, I3{}, d);
+            step(I2{}, I3{}, d++);
+            for (; d <= ND; ++d) step(I2{}, I2{}, d);
+            step(I0{}, I2{}, d++);
+        } else {
+            for (; d <= last0; ++d) step(I1{}, I1{}, d);
+            step(I0{}, I1{}, d++);
         }
-        for (; d <= ND + 1; ++d) step(std::integral_constant<int, 0>{}, d);
+        for (; d <= ND + 3; ++d) step(I0{}, I0{}, d);
     }
 
 #ifdef IFL_STAMPS

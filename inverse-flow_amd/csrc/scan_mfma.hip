@@ -125,17 +125,11 @@ __device__ __forceinline__ void lgkm_wait_n(int n)
     __builtin_amdgcn_sched_barrier(0); // nothing that consumes the data may be scheduled above the wait
 }
 
-// "all but the BASE+k youngest vector-memory operations of this wave are complete", LDS drained, then the
-// workgroup barrier.  The count is exact (see the step body) and wave-uniform; k = 0..8.
-template <int BASE> __device__ __forceinline__ void wait_vm_then_barrier(int k)
+// "all but the N youngest vector-memory operations of this wave are complete", LDS drained, then the workgroup
+// barrier.  N is exact and constant: every step issues the same number of DMAs and stores (see the step body).
+template <int N> __device__ __forceinline__ void wait_vm_then_barrier()
 {
-#define IFL_W(K) \
-    case K: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(BASE + K) : "memory"); break;
-    switch (__builtin_amdgcn_readfirstlane(k)) {
-        IFL_W(0) IFL_W(1) IFL_W(2) IFL_W(3) IFL_W(4) IFL_W(5) IFL_W(6) IFL_W(7) IFL_W(8)
-    default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-    }
-#undef IFL_W
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
 // Development aid (tools/stamps.py; build with HIPCC_EXTRA=-DIFL_STAMPS): per-wave cycle counts of the sections
@@ -160,6 +154,7 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
                                                                     float *__restrict__ zout,
                                                                     const half8 *__restrict__ apack, int H, int W,
                                                                     int rh, int rw, int *__restrict__ flags,
+                                                                    float *__restrict__ sink,
                                                                     const float *__restrict__ wf32, Geom geom,
                                                                     unsigned *__restrict__ amax)
 {
@@ -221,20 +216,24 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
     const unsigned voff = (unsigned)((size_t)cl * H * W * sizeof(float)); // per-lane byte offset of its channel
     const char *xg = (const char *)xin + (size_t)b * C * H * W * sizeof(float);
     char *zg = (char *)zout + (size_t)b * C * H * W * sizeof(float);
+    // Row operations of a step (G DMAs of x quads, G stores of z quads) are wave-uniform, but scalar arithmetic is
+    // the most expensive thing a lone wave can issue (measured: 8.4 cycles per SALU instruction, 5.3 per VALU,
+    // tools/issue_rate_probe.hip).  Lane j < 2G therefore computes operation j's addresses with vector
+    // instructions, and each operation picks its values up with v_readlane.  Per-lane constants of that stage:
+    const bool ro_dma = lane < G;
+    const int ro_i = lane < G ? lane : (lane < 2 * G ? lane - G : 0);
+    const int ro_hb = 4 * (wave + Cfg::NWAVES * ro_i); // first row of the operation's row class
+    const int ro_ko = ro_dma ? 3 : -5;                 // first column of the quad = d + ko - h (rows h = d-1 mod 4 are due)
+    const unsigned long long ro_base = ro_dma ? (unsigned long long)xg : (unsigned long long)zg;
+    const unsigned long long ro_bad = ro_dma ? (unsigned long long)xg : (unsigned long long)sink; // no quad due
+    const int ro_lds = ro_dma ? (int)ldsbase + Cfg::OFF_XS : (int)ldsbase + Cfg::OFF_ZQ;
     // byte offset of the quad (row hr, columns wq..wq+3) in a stored channel plane = gbase + hr*grow + wq*gcol
     const int grow = rh ? -4 * W : 4 * W, gcol = rw ? -4 : 4;
     const int gbase = (rh ? (H - 1) * 4 * W : 0) + (rw ? (W - 4) * 4 : 0);
 
-    int nst[2] = {0, 0};    // store instructions this wave issued in the previous two steps
     float rmax = 0.f;       // max |r| this lane put into the ring: beyond the fp16 range the image is redone in fp32
     float zmax = 0.f;       // max |z| this lane stored (handed to the weight-gradient kernel as its prescale)
-    int qprev = 0, qprev2 = 0; // in-row staging offsets (parity, position in the quad) of the two previous steps' columns
-    floatx4 zh[NTILE], zm[NTILE]; // z product of the previous step, written to the staging area during this one
-#pragma unroll
-    for (int T = 0; T < NTILE; ++T) {
-        zh[T] = floatx4{0.f, 0.f, 0.f, 0.f};
-        zm[T] = floatx4{0.f, 0.f, 0.f, 0.f};
-    }
+    int qprev = 0;          // in-row staging offset (parity, position in the quad) of the previous step's column
     // kernel arguments used in the loop, held in scalar registers (a reload would wait on the LDS counter)
     int Hs = H, Ws = W;
     asm volatile("" : "+s"(Hs), "+s"(Ws));
@@ -280,8 +279,21 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
     //   leading  <- z of the previous step -> staging, completed z quads -> global (store role)
     //   critical <- address arithmetic + issue of the x quads needed three steps from now (DMA role)
     //   trailing <- the chain's epilogue r_d = x + acc -> split fp16 -> ring
-    auto step = [&](auto mask_c, auto pmask_c, const int d) {
-        constexpr int MASK = decltype(mask_c)::value, PMASK = decltype(pmask_c)::value;
+    // row operations of step d, lane-parallel (see the per-lane constants above); computed one step ahead
+    int ro_alo, ro_ahi, ro_loff, ro_okm;
+    auto ro_stage = [&](const int d) {
+        const int hr = ((d - 1) & 3) + ro_hb;
+        const int wq = d + ro_ko - hr;
+        const bool ok = hr < Hs && (unsigned)wq < (unsigned)Ws;
+        const unsigned goff = (unsigned)(gbase + __mul24(hr, grow) + __mul24(wq, gcol));
+        const unsigned long long a = ok ? ro_base + goff : ro_bad;
+        ro_alo = (int)(unsigned)a;
+        ro_ahi = (int)(unsigned)(a >> 32);
+        ro_loff = ro_lds + __mul24(hr, Cfg::XROWB) + ((wq >> 2) & 1) * (C * 16);
+        ro_okm = ok ? -1 : 0;
+    };
+    auto step = [&](auto mask_c, const int d) {
+        constexpr int MASK = decltype(mask_c)::value;
         constexpr int NA = (MASK & 1) + ((MASK >> 1) & 1);
         constexpr int NDH = KH < 2 ? KH : 2;
         constexpr int PER = NA * NQ * 2; // reads per fragment set
@@ -289,11 +301,15 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
         const int srcoff = ((d + 1) & 1) * SLOTB; // ring slot of diagonal d-1 (slot = diagonal mod 2)
         const int dstoff = (d & 1) * SLOTB;       // ring slot of diagonal d
         IFL_STAMP(7); // loop control
+        auto ro_ptr = [&](int j) -> char * {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane(ro_alo, j), hi = (unsigned)__builtin_amdgcn_readlane(ro_ahi, j);
+            return (char *)(((unsigned long long)hi << 32) | lo);
+        };
 
         // The quads this wave DMA'd three steps ago must have landed before anyone reads them below: younger
-        // than those are exactly the stores and DMAs of steps d-2 and d-1 (a step issues its stores first).
-        // Then the barrier: r of diagonal d-1 and the z staged in step d-1 are complete in LDS.
-        wait_vm_then_barrier<2 * G>(nst[0] + nst[1]);
+        // than those are exactly the G stores and G DMAs of each of the steps d-2 and d-1 (a step issues its
+        // stores first).  Then the barrier: r of diagonal d-1 and the z staged in step d-1 are complete in LDS.
+        wait_vm_then_barrier<4 * G>();
         IFL_STAMP(1); // wait + barrier
 
         // in-row staging offset of this step's column w = d - h: the same for all tiles (rows 16 apart)
@@ -302,8 +318,7 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
 
         // ---- LDS requests, oldest first: staged z quads (store role), x of this step, fragments.  They are
         //      numbered so that they can be issued a few at a time between the first leading MFMAs. ----------------
-        // store role: rows h = d-2 (mod 4) completed a quad of z with diagonal d-3 (staged one step ago)
-        const int ps = (d - 2) & 3;
+        // store role: rows h = d-1 (mod 4) completed a quad of z with diagonal d-2 (staged one step ago)
         floatx4_ sv[G];
         floatx2 xq[NTILE][2];
         half8 Fh[NTILE][2][NQ], Fl[NTILE][2][NQ];
@@ -312,11 +327,8 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
             int c = 0;
 #pragma unroll
             for (int i = 0; i < G; ++i)
-                if (c++ == j) {
-                    const int hr = ps + 4 * (wave + Cfg::NWAVES * i);
-                    const int wq = d - 6 - hr; // first column of the quad (any value: the read stays inside the staging area)
-                    lds_read_f32x4(sv[i], ldsbase + Cfg::OFF_ZQ + hr * Cfg::XROWB + ((wq >> 2) & 1) * (C * 16) + cl * 16);
-                }
+                if (c++ == j) // (any quad: the read stays inside the staging area)
+                    lds_read_f32x4(sv[i], (unsigned)__builtin_amdgcn_readlane(ro_loff, G + i) + cl * 16);
             if constexpr (MASK != 0) {
 #pragma unroll
                 for (int T = 0; T < NTILE; ++T)
@@ -345,20 +357,24 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
 
         // A(t) x {hi, lo} fragments of all active tiles -> accumulator tgt; dependent MFMAs kept apart
         // order: per k-step the hi.hi and hi.lo products of all tiles, then the lo.hi products
-        auto mf_one = [&](int t, const auto &fh, const auto &fl, int dh, int tgt, int k) {
+        // init: the group is the first to touch its accumulator (a diagonal's first contribution): start from zero
+        auto mf_one = [&](int t, const auto &fh, const auto &fl, int dh, int tgt, int k, bool init = false) {
             int c = 0;
+            const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
 #pragma unroll
                 for (int T = 0; T < NTILE; ++T)
                     if (MASK & (1 << T))
                         if (c++ == k)
-                            ahi[T][tgt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], fh(T, dh, q), ahi[T][tgt], 0, 0, 0);
+                            ahi[T][tgt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], fh(T, dh, q),
+                                                                                 (init && q == 0) ? zero : ahi[T][tgt], 0, 0, 0);
 #pragma unroll
                 for (int T = 0; T < NTILE; ++T)
                     if (MASK & (1 << T))
                         if (c++ == k)
-                            amid[T][tgt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], fl(T, dh, q), amid[T][tgt], 0, 0, 0);
+                            amid[T][tgt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], fl(T, dh, q),
+                                                                                  (init && q == 0) ? zero : amid[T][tgt], 0, 0, 0);
             }
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
@@ -368,19 +384,21 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
                         if (c++ == k)
                             amid[T][tgt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][1], fh(T, dh, q), amid[T][tgt], 0, 0, 0);
         };
-        auto mf = [&](int t, const auto &fh, const auto &fl, int dh, int tgt) {
+        auto mf = [&](int t, const auto &fh, const auto &fl, int dh, int tgt, bool init = false) {
 #pragma unroll
-            for (int k = 0; k < 3 * NQ * NA; ++k) mf_one(t, fh, fl, dh, tgt, k);
+            for (int k = 0; k < 3 * NQ * NA; ++k) mf_one(t, fh, fl, dh, tgt, k, init);
         };
         auto fence = [&]() { __builtin_amdgcn_sched_barrier(0); };
         // scheduling pattern for the region since the last fence: `lead` MFMAs, then NM x (1 MFMA, NV others)
-        auto weave = [&](auto lead_c, auto nm_c, auto nv_c) {
+        // (each region gets its own pipeline id: groups of one id are matched across the whole basic block)
+        auto weave = [&](auto id_c, auto lead_c, auto nm_c, auto nv_c) {
+            constexpr int ID = decltype(id_c)::value;
             constexpr int LEAD = decltype(lead_c)::value, NM = decltype(nm_c)::value, NV = decltype(nv_c)::value;
-            if constexpr (LEAD > 0) __builtin_amdgcn_sched_group_barrier(0x008, LEAD, 0);
+            if constexpr (LEAD > 0) __builtin_amdgcn_sched_group_barrier(0x008, LEAD, ID);
 #pragma unroll
             for (int k = 0; k < NM; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x296, NV, 0); // VALU | SALU | VMEM | DS
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, ID);
+                __builtin_amdgcn_sched_group_barrier(0x296, NV, ID); // VALU | SALU | VMEM | DS
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -389,47 +407,41 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
         auto f1h = [&](int T, int dh, int q) -> const half8 & { return Fh[T][dh][q]; };
         auto f1l = [&](int T, int dh, int q) -> const half8 & { return Fl[T][dh][q]; };
 
-        // ---- chunk: z of diagonal d-2 (computed one step ago) -> staging, at that column's in-row offset
-        //      (columns outside the image land in quads that are not live: before a row's first quad, or in the
-        //      parity its last quad does not use) -----------------------------------------------------------
+        // ---- chunk: z of diagonal d-1 -> staging, at that column's in-row offset (columns outside the image land
+        //      in quads that are not live: before a row's first quad, or in the parity its last quad does not use)
+        floatx4 zh[NTILE], zm[NTILE];
         auto chunk_zstage = [&]() {
 #pragma unroll
             for (int T = 0; T < NTILE; ++T)
-                if (PMASK & (1 << T)) {
-                    unsigned char *zp = zq + xadr[T] + qprev2;
+                if (MASK & (1 << T)) {
+                    unsigned char *zp = zq + xadr[T] + qprev;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) *(float *)(zp + r * 16) = zh[T][r] + zm[T][r] * LO_INV;
                 }
         };
         // ---- chunk: store role ----------------------------------------------------------------------------
-        int nstore = 0;
+        // Every step issues exactly G stores, so that the vector-memory counter can be waited on with a constant:
+        // a row without a finished quad stores its (meaningless) staging read to the workgroup's sink instead.
         auto chunk_store = [&]() {
             lgkm_wait_n(NYOUNG); // the staged quads have landed (they are the oldest requests)
 #pragma unroll
             for (int i = 0; i < G; ++i) {
-                const int hr = ps + 4 * (wave + Cfg::NWAVES * i);
-                const int wq = d - 6 - hr;
-                if (hr < Hs && (unsigned)wq < (unsigned)Ws) { // wave-uniform
-                    nstore += 1;
-                    char *dstp = zg + (gbase + hr * grow + wq * gcol); // wave-uniform
-                    if (C == 64 || lane < C) {
-                        *(floatx4_ *)(dstp + voff) = sv[i];
-                        zmax = fmaxf(zmax, fmaxf(fmaxf(fabsf(sv[i][0]), fabsf(sv[i][1])), fmaxf(fabsf(sv[i][2]), fabsf(sv[i][3]))));
-                    }
+                char *dstp = ro_ptr(G + i); // wave-uniform: the quad's place in z, or the sink
+                const unsigned okm = (unsigned)__builtin_amdgcn_readlane(ro_okm, G + i);
+                if (C == 64 || lane < C) {
+                    *(floatx4_ *)(dstp + voff) = sv[i];
+                    const float m = fmaxf(fmaxf(fabsf(sv[i][0]), fabsf(sv[i][1])), fmaxf(fabsf(sv[i][2]), fabsf(sv[i][3])));
+                    zmax = fmaxf(zmax, __uint_as_float(__float_as_uint(m) & okm));
                 }
             }
         };
         // ---- chunk: DMA role, x quads needed three steps from now (unconditional: exact VM operation count) -
         auto chunk_dma = [&](int i) {
-            const int hr = ((d - 1) & 3) + 4 * (wave + Cfg::NWAVES * i); // rows h = d-1 (mod 4) are one step into a quad of x
-            const int wq = d - hr + 3;
-            const int okm = (hr < Hs && (unsigned)wq < (unsigned)Ws) ? -1 : 0;
-            const int off = (gbase + hr * grow + wq * gcol) & okm;
-            const char *src = xg + off; // wave-uniform
-            unsigned char *dst = xs + hr * Cfg::XROWB + ((wq >> 2) & 1) * (C * 16); // lane c lands at +16c
+            const char *src = ro_ptr(i); // wave-uniform: the quad, or the image's first one when none is due
+            const unsigned dst = (unsigned)__builtin_amdgcn_readlane(ro_loff, i); // lane c lands at +16c
             if (C == 64 || lane < C)
                 __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + voff),
-                                                 (void __attribute__((address_space(3))) *)dst, 16, 0, 0);
+                                                 (void __attribute__((address_space(3))) *)(size_t)dst, 16, 0, 0);
         };
         // ---- chunk: epilogue of tile T (the chain): r_d = x + acc[0] -> split fp16 -> ring; then the accumulators
         //      rotate: diagonal d+1 becomes the head, a fresh one joins for d+3 -------------------------------
@@ -461,44 +473,40 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
 #pragma unroll
             for (int j = 0; j < NREQ; ++j) request(j);
             fence();
-            chunk_zstage();
             chunk_store();
 #pragma unroll
             for (int i = 0; i < G; ++i) chunk_dma(i);
+            ro_stage(d + 1);
             fence();
         } else {
             // ---- leading: taps (2, dw) of r_{d-2}; their targets are diagonals d-2+2+dw = d + dw -----------
             if constexpr (KH > 2) {
-                // the first group carries the LDS requests (inline asm: placed by hand, two behind each MFMA)
-                constexpr int RPM = (NREQ + GM - 1) / GM;
+                // the first two groups carry the LDS requests (inline asm: placed by hand, one behind each MFMA:
+                // measured 21 cycles for MFMA + ds_read_b128, 36.5 for MFMA + two)
+                constexpr int NLEADM = (KW > 1 ? 2 : 1) * GM;
+                constexpr int RPM = (NREQ + NLEADM - 1) / NLEADM;
 #pragma unroll
-                for (int k = 0; k < GM; ++k) {
-                    mf_one(2 * KW + 0, f2h, f2l, 0, 0, k);
+                for (int k = 0; k < NLEADM; ++k) {
+                    if (k < GM) mf_one(2 * KW + 0, f2h, f2l, 0, 0, k);
+                    else mf_one(2 * KW + 1, f2h, f2l, 0, 1, k - GM);
+                    // (MFMAs are pure: tie the result to an opaque statement, or they sink below the requests)
+#pragma unroll
+                    for (int T = 0; T < NTILE; ++T)
+                        if (MASK & (1 << T)) asm volatile("" : "+a"(ahi[T][k < GM ? 0 : 1]), "+a"(amid[T][k < GM ? 0 : 1]));
                     fence();
 #pragma unroll
                     for (int j = k * RPM; j < (k + 1) * RPM && j < NREQ; ++j) request(j);
                     fence();
                 }
-                if constexpr (KW > 1) mf(2 * KW + 1, f2h, f2l, 0, 1);
-                chunk_zstage();
-                weave(N0{}, NGM{}, std::integral_constant<int, 3>{});
+                if constexpr (KW > 2) mf(2 * KW + 2, f2h, f2l, 0, 2, true); // first contribution to diagonal d+2
                 chunk_store();
-                fence();
-                if constexpr (KW > 2) mf(2 * KW + 2, f2h, f2l, 0, 2);
 #pragma unroll
                 for (int i = 0; i < G; ++i) chunk_dma(i);
-                weave(N0{}, NGM{}, std::integral_constant<int, 4>{});
-                asm volatile("s_nop 7" ::: "memory"); // margin between the last operand read and the reload below
-                // this step's dh=2 fragments of r_{d-1}, for the next step's leading MFMAs
-#pragma unroll
-                for (int T = 0; T < NTILE; ++T)
-                    if (MASK & (1 << T)) lds_read_set<NQ, 0>(F2h[T], F2l[T], radr[T][2] + srcoff);
-                fence();
+                weave(std::integral_constant<int, 2>{}, N0{}, NGM{}, std::integral_constant<int, 3>{});
             } else {
 #pragma unroll
                 for (int j = 0; j < NREQ; ++j) request(j);
                 fence();
-                chunk_zstage();
                 chunk_store();
 #pragma unroll
                 for (int i = 0; i < G; ++i) chunk_dma(i);
@@ -506,9 +514,36 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
             }
             IFL_STAMP(2); // read issue + leading MFMAs (+ all reads landed, when stamping)
             // ---- critical: taps (0,1) and (1,0) of r_{d-1} -> diagonal d -----------------------------------------
+            // The dh=2 fragments of r_{d-1} (next step's leading operands; single-buffered: every MFMA that reads the
+            // old ones has been issued) are requested between the first critical MFMAs.
+            auto request2 = [&](int j) {
+                int c = 0;
+#pragma unroll
+                for (int T = 0; T < NTILE; ++T)
+                    if (MASK & (1 << T)) {
+                        const unsigned fa = radr[T][KH > 2 ? 2 : 0] + srcoff;
+                        if (c++ == j) lds_read_b128_o<0>(F2h[T][0], fa);
+                        if (c++ == j) lds_read_b128_o<4 * 256>(F2l[T][0], fa);
+                        if constexpr (NQ == 2) {
+                            if (c++ == j) lds_read_b128_o<8 * 256>(F2h[T][1], fa);
+                            if (c++ == j) lds_read_b128_o<12 * 256>(F2l[T][1], fa);
+                        }
+                    }
+            };
             if constexpr (KW > 1) {
-                lgkm_wait_n((NDH - 1) * PER + NRD2); // the dh=0 fragments of all tiles have landed
-                mf(1, f1h, f1l, 0, 0);
+                lgkm_wait_n((NDH - 1) * PER); // the dh=0 fragments of all tiles have landed
+#pragma unroll
+                for (int k = 0; k < GM; ++k) {
+                    mf_one(1, f1h, f1l, 0, 0, k);
+                    if constexpr (KH > 2) {
+#pragma unroll
+                        for (int T = 0; T < NTILE; ++T)
+                            if (MASK & (1 << T)) asm volatile("" : "+a"(ahi[T][0]), "+a"(amid[T][0]));
+                        fence();
+                        if (k < PER) request2(k);
+                        fence();
+                    }
+                }
                 fence();
             }
             if constexpr (KH > 1) {
@@ -529,9 +564,7 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
                     ahi[T][0] = ahi[T][1];
                     amid[T][0] = amid[T][1];
                     ahi[T][1] = ahi[T][2];
-                    amid[T][1] = amid[T][2];
-                    ahi[T][2] = floatx4{0.f, 0.f, 0.f, 0.f};
-                    amid[T][2] = floatx4{0.f, 0.f, 0.f, 0.f};
+                    amid[T][1] = amid[T][2]; // ([2] is dead until the group that opens the next diagonal initialises it)
                 }
             auto epi = [&](int T) {
                 if (MASK & (1 << T)) {
@@ -543,30 +576,31 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
                     amid[T][0] = sm;
                 }
             };
-            int ntr = 0; // trailing groups issued so far: the epilogues ride on the first and the second
+            // MFMA groups in issue order: the z product first (its results are staged within this step), then the
+            // taps.  Riders, one per group: epilogue of tile 0, of tile 1, z staging, next step's row operations;
+            // riders without a group run behind the last one.
+            int ntr = 0;
+            auto rider = [&](int k) {
+                if (k == 0) epi(0);
+                if (k == 1 && NTILE > 1) epi(1);
+                if (k == 2) chunk_zstage();
+                if (k == 3) ro_stage(d + 1);
+            };
             auto after_group = [&]() {
                 constexpr int LEADM = GM < 4 ? GM : 4; // the head's last MFMA needs a few issue slots to finish
-                if (ntr == 0) {
-                    epi(0);
-                    weave(std::integral_constant<int, LEADM>{}, std::integral_constant<int, GM - LEADM>{},
-                          std::integral_constant<int, 5>{});
-                } else if (ntr == 1 && NTILE > 1) {
-                    epi(1);
-                    weave(N0{}, NGM{}, std::integral_constant<int, 4>{});
-                } else {
-                    fence();
-                }
+                rider(ntr);
+                if (ntr == 0)
+                    weave(std::integral_constant<int, 3>{}, std::integral_constant<int, LEADM>{},
+                          std::integral_constant<int, GM - LEADM>{}, std::integral_constant<int, 5>{});
+                else if (ntr == 1)
+                    weave(std::integral_constant<int, 4>{}, N0{}, NGM{}, std::integral_constant<int, 4>{});
+                else if (ntr == 2)
+                    weave(std::integral_constant<int, 5>{}, N0{}, NGM{}, std::integral_constant<int, 3>{});
+                else
+                    weave(std::integral_constant<int, 6>{}, N0{}, NGM{}, std::integral_constant<int, 3>{});
                 ++ntr;
             };
-#pragma unroll
-            for (int dh = 0; dh < NDH; ++dh)
-#pragma unroll
-                for (int dw = 0; dw < KW; ++dw)
-                    if (dh + dw >= 2) {
-                        mf(dh * KW + dw, f1h, f1l, dh, dh + dw - 2);
-                        after_group();
-                    }
-            // z product (its own accumulators, carried to the next step's staging chunk)
+            // z product
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
 #pragma unroll
@@ -589,41 +623,47 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
                     if (MASK & (1 << T))
                         zm[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[NS - 1][q][1], Fh[T][0][q], zm[T], 0, 0, 0);
             after_group();
+#pragma unroll
+            for (int dh = 0; dh < NDH; ++dh)
+#pragma unroll
+                for (int dw = 0; dw < KW; ++dw)
+                    if (dh + dw >= 2) {
+                        // (without a dh=2 row the farthest tap is this one: it opens its diagonal)
+                        mf(dh * KW + dw, f1h, f1l, dh, dh + dw - 2, KH < 3 && dh + dw == KH + KW - 2);
+                        after_group();
+                    }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k >= ntr) rider(k);
+            fence();
             IFL_STAMP(5); // trailing MFMAs issued
         }
 
-        qprev2 = qprev;
         qprev = qcur;
-        nst[1] = nst[0];
-        nst[0] = nstore;
         IFL_STAMP(6); // bookkeeping
     };
 
     // A tile's window runs from two steps before its first pixel (the dh=2 fragments and the early pushes) to
     // the step after its last one (the z product of the last diagonal): the sets of active tiles come in the
-    // order {}, {0}, {0,1}, {1}, {} -- one loop per set (its first step peeled: the previous set's z products
-    // are still to be staged), so that no control flow merges inside a step.  Two more steps drain the staging.
+    // order {}, {0}, {0,1}, {1}, {} -- one loop per set, so that no control flow merges inside a step.  The last
+    // step stores the quads staged by the one before.
     {
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
         const int last0 = (15 + W - 1 < ND - 1 ? 15 + W - 1 : ND - 1) + 1; // last step of tile 0
         int d = -3;
-        step(I0{}, I0{}, d++);
-        step(I1{}, I0{}, d++);
+        ro_stage(d);
+        step(I0{}, d++);
         if constexpr (NTILE == 2) {
             using I2 = std::integral_constant<int, 2>;
             using I3 = std::integral_constant<int, 3>;
-            for (; d < 14; ++d) step(I1{}, I1{}, d);
-            step(I3{}, I1{}, d++);
-            for (; d <= last0; ++d) step(I3{}, I3{}, d);
-            step(I2{}, I3{}, d++);
-            for (; d <= ND; ++d) step(I2{}, I2{}, d);
-            step(I0{}, I2{}, d++);
+            for (; d < 14; ++d) step(I1{}, d);
+            for (; d <= last0; ++d) step(I3{}, d);
+            for (; d <= ND; ++d) step(I2{}, d);
         } else {
-            for (; d <= last0; ++d) step(I1{}, I1{}, d);
-            step(I0{}, I1{}, d++);
+            for (; d <= last0; ++d) step(I1{}, d);
         }
-        for (; d <= ND + 3; ++d) step(I0{}, I0{}, d);
+        for (; d <= ND + 2; ++d) step(I0{}, d);
     }
 
 #ifdef IFL_STAMPS
@@ -836,7 +876,7 @@ int launch_foldpack_mfma(const float *w, void *out0, float *wf0, void *out1, flo
 }
 
 template <int C, int KH, int KW, int NTILE>
-static int launch_one(const float *x, float *z, const void *apack, const Geom &g, int rh, int rw, int *flags,
+static int launch_one(const float *x, float *z, const void *apack, const Geom &g, int rh, int rw, int *flags, float *sink,
                       const float *wf32, unsigned *amax, hipStream_t s)
 {
     using Cfg = ScanCfg<C, KH, KW, NTILE>;
@@ -856,17 +896,17 @@ static int launch_one(const float *x, float *z, const void *apack, const Geom &g
     }
 #endif
     hipLaunchKernelGGL((k_scan_mfma<C, KH, KW, NTILE>), dim3(g.B), dim3(Cfg::THREADS), Cfg::LDSB, s, x, z,
-                       (const half8 *)apack, g.H, g.W, rh, rw, flags, wf32, g, amax);
+                       (const half8 *)apack, g.H, g.W, rh, rw, flags, sink, wf32, g, amax);
     IFL_HIP(hipGetLastError());
     return IFL_OK;
 }
 
 int launch_scan_mfma(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, int *flags,
-                     const float *wf32, unsigned *amax, hipStream_t s)
+                     float *sink, const float *wf32, unsigned *amax, hipStream_t s)
 {
     const int nt = g.H <= 16 ? 1 : 2;
 #define IFL_CASE(CC, KK, NN) \
-    if (g.C == CC && g.KH == KK && g.KW == KK && nt == NN) return launch_one<CC, KK, KK, NN>(x, z, apack, g, rh, rw, flags, wf32, amax, s);
+    if (g.C == CC && g.KH == KK && g.KW == KK && nt == NN) return launch_one<CC, KK, KK, NN>(x, z, apack, g, rh, rw, flags, sink, wf32, amax, s);
     IFL_CASE(64, 3, 1)
     IFL_CASE(64, 3, 2)
     IFL_CASE(32, 3, 1)

@@ -24,6 +24,8 @@
 // tools/mfma_f16_denorm_probe.hip) after a power-of-two per-tensor prescale that puts max|v| at 2^6,
 // three MFMAs per k-step (hi*hi + hi*lo + lo*hi), fp32 accumulation.
 #include "ifl_common.h"
+#include <type_traits>
+#include <stdlib.h>
 
 namespace ifl {
 
@@ -119,6 +121,21 @@ template <int J> __device__ __forceinline__ half8 shift_frag(const half8 &f, uns
     return __builtin_bit_cast(half8, o);
 }
 
+#ifdef IFL_STAMPS
+__device__ unsigned long long *g_wstamps = nullptr;
+#define IFL_WSTAMP(k)                                                \
+    do {                                                             \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          \
+        wst[k] += t_ - wlast;                                        \
+        wlast = t_;                                                  \
+    } while (0)
+#else
+#define IFL_WSTAMP(k) \
+    do {              \
+    } while (0)
+#endif
+
 // C channels, KHxKW taps (KW <= 3), NKS = W/16 k-steps per image row
 template <int C, int KH, int KW, int NKS>
 __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a, const float *__restrict__ bb,
@@ -145,6 +162,9 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#ifdef IFL_STAMPS
+    unsigned long long wst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wlast = __builtin_amdgcn_s_memtime();
+#endif
 
     const int rgroups = (H + WG_RPW - 1) / WG_RPW;
     const int task = split * 4 + wv; // (image, row group)
@@ -167,49 +187,64 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
 #pragma unroll
                     for (int j = 0; j < 8; ++j) Bz[i][ks][hl][j] = (_Float16)0.f;
 
-        // halo: the KH-1 rows of bb before the first row of this slice
+        // halo: the KH-1 rows of bb before the first row of this slice (loads issued together, then converted)
+        {
+            floatx4 hv[KH][NKS][2];
 #pragma unroll
-        for (int i = KH - 1; i >= 1; --i) {
-            const int r = r_first - sg * i;
-            if (r >= 0 && r < H) {
+            for (int i = KH - 1; i >= 1; --i) {
+                const int r = r_first - sg * i;
+                const int rc = (r >= 0 && r < H) ? r : r_first;
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
-                    const floatx4 v0 = *(const floatx4 *)(bpz + (size_t)r * W + 16 * ks);
-                    const floatx4 v1 = *(const floatx4 *)(bpz + (size_t)r * W + 16 * ks + 4);
-                    split8(v0, v1, sb, Bz[i][ks][0], Bz[i][ks][1]);
+                    hv[i][ks][0] = *(const floatx4 *)(bpz + (size_t)rc * W + 16 * ks);
+                    hv[i][ks][1] = *(const floatx4 *)(bpz + (size_t)rc * W + 16 * ks + 4);
+                }
+            }
+#pragma unroll
+            for (int i = KH - 1; i >= 1; --i) {
+                const int r = r_first - sg * i;
+                if (r >= 0 && r < H) {
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) split8(hv[i][ks][0], hv[i][ks][1], sb, Bz[i][ks][0], Bz[i][ks][1]);
                 }
             }
         }
 
-        // raw prefetch registers for the current row
-        floatx4 ra[NKS][2], rb[NKS][2];
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            ra[ks][0] = *(const floatx4 *)(ap + (size_t)r_first * W + 16 * ks);
-            ra[ks][1] = *(const floatx4 *)(ap + (size_t)r_first * W + 16 * ks + 4);
-            rb[ks][0] = *(const floatx4 *)(bpz + (size_t)r_first * W + 16 * ks);
-            rb[ks][1] = *(const floatx4 *)(bpz + (size_t)r_first * W + 16 * ks + 4);
-        }
-
-        for (int step = 0; step < nrows; ++step) {
-            const int r = r_first + sg * step;
-            // convert the row that was prefetched, then prefetch the next one
-            half8 Au[NKS][2];
+        // Software pipeline (one wave per SIMD: nothing else hides latency or the conversion work):
+        //   iteration `step` multiplies row r (fragments Au, Bz converted one iteration ago) while it converts the
+        //   raw registers of row r+1 in the MFMAs' shadow and then reloads them with row r+3.  Two raw sets
+        //   alternate (loop unrolled by two), so a load has two iterations to land and nothing ever waits on
+        //   a load it has just issued.
+        floatx4 ra[2][NKS][2], rb[2][NKS][2];
+        auto fetch = [&](auto set_c, int k) { // row number k of the slice (rows past it: re-read a valid row, never used)
+            constexpr int SET = decltype(set_c)::value;
+            const int r = r_first + sg * (k < nrows ? k : nrows - 1);
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                split8(ra[ks][0], ra[ks][1], sa, Au[ks][0], Au[ks][1]);
-                split8(rb[ks][0], rb[ks][1], sb, Bz[0][ks][0], Bz[0][ks][1]);
+                ra[SET][ks][0] = *(const floatx4 *)(ap + (size_t)r * W + 16 * ks);
+                ra[SET][ks][1] = *(const floatx4 *)(ap + (size_t)r * W + 16 * ks + 4);
+                rb[SET][ks][0] = *(const floatx4 *)(bpz + (size_t)r * W + 16 * ks);
+                rb[SET][ks][1] = *(const floatx4 *)(bpz + (size_t)r * W + 16 * ks + 4);
             }
-            if (step + 1 < nrows) {
-                const int rn = r + sg;
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        half8 Au[NKS][2];
+        fetch(S0{}, 0);
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    ra[ks][0] = *(const floatx4 *)(ap + (size_t)rn * W + 16 * ks);
-                    ra[ks][1] = *(const floatx4 *)(ap + (size_t)rn * W + 16 * ks + 4);
-                    rb[ks][0] = *(const floatx4 *)(bpz + (size_t)rn * W + 16 * ks);
-                    rb[ks][1] = *(const floatx4 *)(bpz + (size_t)rn * W + 16 * ks + 4);
-                }
-            }
+        for (int ks = 0; ks < NKS; ++ks) {
+            split8(ra[0][ks][0], ra[0][ks][1], sa, Au[ks][0], Au[ks][1]);
+            split8(rb[0][ks][0], rb[0][ks][1], sb, Bz[0][ks][0], Bz[0][ks][1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(S1{}, 1); // row 1 -> set 1 (converted in iteration 0), row 2 -> set 0 (converted in iteration 1)
+        fetch(S0{}, 2);
+        __builtin_amdgcn_sched_barrier(0);
+
+        IFL_WSTAMP(0); // prologue
+        // iteration `step`: converts set SET = (step+1) mod 2 (row step+1), reloads it with row step+3
+        auto row_step = [&](auto set_c, const int step) {
+            constexpr int SET = decltype(set_c)::value;
             // heads of the next 8-column block, exchanged across the two wave halves:
             // a lane with hh=0 needs the hh=1 lane's block of the same k-step, a lane with hh=1 the
             // hh=0 lane's block of the next k-step (zero past the row end)
@@ -221,28 +256,53 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
                     const unsigned own = __builtin_bit_cast(uintx4, Au[ks][hl])[0];
                     const unsigned nxt = ks + 1 < NKS ? __builtin_bit_cast(uintx4, Au[ks + 1 < NKS ? ks + 1 : ks][hl])[0] : 0u;
                     const unsigned send = hh ? own : nxt;
-                    head[ks][hl] = (unsigned)__shfl_xor((int)send, 32, 64);
+                    // exchange across the wave halves without the LDS crossbar: after the swap the first result holds
+                    // the low half's values in both halves, the second the high half's
+                    const auto sw = __builtin_amdgcn_permlane32_swap(send, send, false, false);
+                    head[ks][hl] = hh ? sw[0] : sw[1];
                 }
             // note: the hh=1 lane of the LAST k-step receives `nxt` of its partner = 0 (row end) as
             // intended; the hh=0 lane receives the partner's own block.
-
-#define IFL_WG_TAPS(J)                                                                                             \
-    {                                                                                                              \
-        half8 As[NKS][2];                                                                                          \
-        _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks) _Pragma("unroll") for (int hl = 0; hl < 2; ++hl)        \
-            As[ks][hl] = shift_frag<J>(Au[ks][hl], head[ks][hl]);                                                  \
-        /* consecutive MFMAs go to different accumulators (rows i of the tap column J): back-to-back MFMAs    */ \
-        /* into one accumulator issue ~1.5x slower from a single wave (tools/mfma_rate_probe.hip)             */ \
-        _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks) _Pragma("unroll") for (int pr = 0; pr < 3; ++pr)        \
-            _Pragma("unroll") for (int i = 0; i < KH; ++i)                                                          \
-                acc[i * KW + J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(As[ks][pr == 2 ? 1 : 0],                   \
-                                                                           Bz[i][ks][pr == 1 ? 1 : 0], acc[i * KW + J], 0, 0, 0); \
-    }
-            IFL_WG_TAPS(0)
-            if constexpr (KW > 1) IFL_WG_TAPS(1)
-            if constexpr (KW > 2) IFL_WG_TAPS(2)
-#undef IFL_WG_TAPS
-
+            half8 As[KW][NKS][2];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) {
+                    As[0][ks][hl] = shift_frag<0>(Au[ks][hl], head[ks][hl]);
+                    if constexpr (KW > 1) As[1][ks][hl] = shift_frag<1>(Au[ks][hl], head[ks][hl]);
+                    if constexpr (KW > 2) As[2][ks][hl] = shift_frag<2>(Au[ks][hl], head[ks][hl]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            IFL_WSTAMP(1); // shifts
+            // the next row's fragments
+            half8 An[NKS][2], Bn[NKS][2];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                split8(ra[SET][ks][0], ra[SET][ks][1], sa, An[ks][0], An[ks][1]);
+                split8(rb[SET][ks][0], rb[SET][ks][1], sb, Bn[ks][0], Bn[ks][1]);
+            }
+            // consecutive MFMAs go to different accumulators (rows i of the tap column j): back-to-back MFMAs into
+            // one accumulator issue ~1.5x slower from a single wave (tools/mfma_rate_probe.hip)
+#pragma unroll
+            for (int j = 0; j < KW; ++j)
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                    for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                        for (int i = 0; i < KH; ++i)
+                            acc[i * KW + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(As[j][ks][pr == 2 ? 1 : 0], Bz[i][ks][pr == 1 ? 1 : 0],
+                                                                                     acc[i * KW + j], 0, 0, 0);
+            // the conversion rides in the MFMAs' shadow: an MFMA holds the matrix pipe for 32 cycles
+#pragma unroll
+            for (int k = 0; k < KW * NKS * 3 * KH; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, SET);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, SET);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            IFL_WSTAMP(3); // MFMAs + conversion of the next row
+            fetch(set_c, step + 3); // (unconditional: a branch would park the loads elsewhere)
+            __builtin_amdgcn_sched_barrier(0);
             // roll the rows of bb
 #pragma unroll
             for (int i = KH - 1; i >= 1; --i)
@@ -250,9 +310,23 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
                 for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
                     for (int hl = 0; hl < 2; ++hl) Bz[i][ks][hl] = Bz[i - 1][ks][hl];
-            (void)r;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) {
+                    Bz[0][ks][hl] = Bn[ks][hl];
+                    Au[ks][hl] = An[ks][hl];
+                }
+            IFL_WSTAMP(2); // loads + roll
+        };
+        int step = 0;
+        for (; step + 1 < nrows; step += 2) {
+            row_step(S1{}, step);
+            row_step(S0{}, step + 1);
         }
+        if (step < nrows) row_step(S1{}, step);
     }
+    IFL_WSTAMP(4);
 
     // ---- tree reduction of the four waves' accumulators through LDS (fixed order) ----------------
     floatx4 *red = (floatx4 *)smem; // [2][NT*4][64] float4
@@ -286,56 +360,67 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
                 red[(t * 4 + v) * 64 + lane] = floatx4{acc[t][4 * v], acc[t][4 * v + 1], acc[t][4 * v + 2], acc[t][4 * v + 3]};
     }
     __syncthreads();
+    IFL_WSTAMP(5); // tree reduction
     if (wv == 0) {
-        // partial[split][t][p][q] with p = 32bp + row, q = 32bq + col (unscaled: the reduce kernel divides)
-        float *out = partial + (size_t)split * NT * C * C;
+        // partial[split][block][t][v][lane] (float4): the accumulator registers as they are -- register 4v+e of lane
+        // (m, hh) is row (e) + 8v + 4hh, column m of the 32x32 block (C/D layout of the 32x32 MFMA); the reduce
+        // kernel undoes the layout.  One 16-byte store per register quad (unscaled: the reduce kernel divides).
+        floatx4 *out = (floatx4 *)partial + ((size_t)split * NB * NB + blk) * NT * 4 * 64;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const floatx4 o = red[(t * 4 + v) * 64 + lane];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int reg = 4 * v + e;
-                    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh; // C/D layout of 32x32 MFMA
-                    out[((size_t)t * C + 32 * bp + row) * C + 32 * bq + m] = acc[t][reg] + o[e];
-                }
+                out[(t * 4 + v) * 64 + lane] =
+                    floatx4{acc[t][4 * v] + o[0], acc[t][4 * v + 1] + o[1], acc[t][4 * v + 2] + o[2], acc[t][4 * v + 3] + o[3]};
             }
     }
+    IFL_WSTAMP(6); // partial store
+#ifdef IFL_STAMPS
+    if (g_wstamps && blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 8; ++k) g_wstamps[wv * 8 + k] = wst[k];
+#endif
 }
 
-// dw[co][ci][kh][kw] = scale/(sa*sb) * sum_splits partial[s][t=(i,j)][p][q], p/q = (co,ci) or (ci,co).
-// Four lanes share one output (each sums every 4th partial, then a fixed-order butterfly): deterministic.
+// dw[co][ci][kh][kw] = scale/(sa*sb) * sum_splits partial[s][block][t=(i,j)][v][lane][e]; the block's (row, column) is
+// (co,ci) or (ci,co).  A thread owns one float4 of the register dump (four rows of one column); four waves share
+// it (each sums every 4th partial, then a fixed-order sum): deterministic.
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ partial, float *__restrict__ dw,
                                                       const unsigned *__restrict__ amax_a,
                                                       const unsigned *__restrict__ amax_b, int nsplit, int C, int KH,
                                                       int KW, int swapped, int top, int left, float scale,
                                                       int mask_mode, int mkh, int mkw)
 {
-    const int NT = KH * KW;
-    const size_t total = (size_t)NT * C * C;
+    const int NT = KH * KW, NB = C / 32;
+    const size_t total4 = (size_t)NB * NB * NT * 4 * 64; // float4 elements of one partial
     const float inv = scale / (pow2_scale(*amax_a) * pow2_scale(*amax_b));
-    const int sub = threadIdx.x >> 6;                                    // wave index = partial residue class
-    const size_t idx = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);     // output element
-    __shared__ float red[4][64];
-    float s = 0.f;
-    if (idx < total)
-        for (int k = sub; k < nsplit; k += 4) s += partial[(size_t)k * total + idx];
+    const int sub = threadIdx.x >> 6;                                // wave index = partial residue class
+    const size_t idx = (size_t)blockIdx.x * 64 + (threadIdx.x & 63); // float4 element
+    __shared__ floatx4 red[4][64];
+    floatx4 s = {0.f, 0.f, 0.f, 0.f};
+    if (idx < total4)
+        for (int k = sub; k < nsplit; k += 4) s += ((const floatx4 *)partial)[(size_t)k * total4 + idx];
     red[sub][threadIdx.x & 63] = s;
     __syncthreads();
-    if (sub == 0 && idx < total) {
+    if (sub == 0 && idx < total4) {
         const int l = threadIdx.x & 63;
         s = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
-        const int q = (int)(idx % C), p = (int)((idx / C) % C), t = (int)(idx / ((size_t)C * C));
+        const int lane = (int)(idx % 64), v = (int)((idx / 64) % 4), t = (int)((idx / 256) % NT), blk = (int)(idx / (256 * (size_t)NT));
+        const int bp = blk / NB, bq = blk % NB, m = lane & 31, hh = lane >> 5;
         const int i = t / KW, j = t % KW;
         const int kh = top ? KH - 1 - i : i, kw = left ? KW - 1 - j : j;
-        const int co = swapped ? q : p, ci = swapped ? p : q;
-        float v = s * inv;
-        if (mask_mode && kh == mkh && kw == mkw) {
-            if (mask_mode == 1 && ci >= co) v = 0.f;
-            if (mask_mode == 2 && ci > co) v = 0.f;
+        const int q = 32 * bq + m;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int p = 32 * bp + e + 8 * v + 4 * hh;
+            const int co = swapped ? q : p, ci = swapped ? p : q;
+            float val = s[e] * inv;
+            if (mask_mode && kh == mkh && kw == mkw) {
+                if (mask_mode == 1 && ci >= co) val = 0.f;
+                if (mask_mode == 2 && ci > co) val = 0.f;
+            }
+            dw[(((size_t)co * C + ci) * KH + kh) * KW + kw] = val;
         }
-        dw[(((size_t)co * C + ci) * KH + kh) * KW + kw] = v;
     }
 }
 
@@ -386,6 +471,12 @@ static int launch_wg(const float *a, const float *bb, float *partial, const unsi
                                     (int)lds));
         attr_done = true;
     }
+#ifdef IFL_STAMPS
+    if (const char *e = getenv("IFL_WSTAMPS")) {
+        unsigned long long *ptr = (unsigned long long *)strtoull(e, nullptr, 0);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wstamps), &ptr, sizeof(ptr));
+    }
+#endif
     hipLaunchKernelGGL((k_wgrad_mfma<C, KH, KW, NKS>), dim3(nsplit * NB * NB), dim3(256), lds, s, a, bb, partial, amax_a,
                        amax_b, B, H, sg, ntask);
     IFL_HIP(hipGetLastError());
@@ -430,8 +521,8 @@ int launch_wgrad_mfma(const float *gz, const float *x, float *dw, void *ws, int 
     if (rc == IFL_EUNSUPPORTED) IFL_FAIL(rc, "launch_wgrad_mfma: no instantiation for C=%d K=%d W=%d", C, KH, W);
     if (rc) return rc;
     const int nsplit = (wgrad_ntask(B, H) + 3) / 4;
-    const size_t total = (size_t)KH * KW * C * C;
-    size_t blocks = (total + 63) / 64;
+    const size_t total4 = (size_t)KH * KW * C * C / 4;
+    size_t blocks = (total4 + 63) / 64;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)blocks), dim3(256), 0, s, partial, dw, amax_gz, amax_x, nsplit, C, KH, KW,
                        swapped, top, left, scale, mask_mode, mkh, mkw);
     IFL_HIP(hipGetLastError());

@@ -1,0 +1,21 @@
+"""Per-section cycle counts of the MFMA weight-gradient kernel (development aid).
+
+    HIPCC_EXTRA=-DIFL_STAMPS python inverse-flow_amd/build.py --force && python tools/wstamps.py
+"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "inverse-flow_amd")); sys.path.insert(0, ROOT)
+import torch
+buf = torch.zeros(4 * 8, dtype=torch.int64, device="cuda")
+os.environ["IFL_WSTAMPS"] = str(buf.data_ptr())
+import invflow_hip as H
+from bench import B, C, HH, WW
+z = torch.randn(B, C, HH, WW, device="cuda"); dx = torch.randn_like(z)
+for _ in range(3):
+    dw = H.dw_from(z, dx, (3, 3))
+torch.cuda.synchronize()
+t = buf.cpu().view(4, 8)
+names = ["prologue", "wait row", "convert+loads", "shift+mfma", "-", "tree reduce", "partial store", "-"]
+for wv in range(4):
+    r = t[wv].tolist()
+    print("wave", wv, {names[k]: r[k] for k in range(7) if names[k] != "-"}, "total", sum(r))

@@ -262,6 +262,7 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
 
 #ifdef IFL_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+    unsigned long long st_mask[4] = {0, 0, 0, 0}, st_cnt[4] = {0, 0, 0, 0};
 #endif
     __syncthreads();
 
@@ -301,6 +302,9 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
         const int srcoff = ((d + 1) & 1) * SLOTB; // ring slot of diagonal d-1 (slot = diagonal mod 2)
         const int dstoff = (d & 1) * SLOTB;       // ring slot of diagonal d
         IFL_STAMP(7); // loop control
+#ifdef IFL_STAMPS
+        const unsigned long long st_t0 = st_last;
+#endif
         auto ro_ptr = [&](int j) -> char * {
             const unsigned lo = (unsigned)__builtin_amdgcn_readlane(ro_alo, j), hi = (unsigned)__builtin_amdgcn_readlane(ro_ahi, j);
             return (char *)(((unsigned long long)hi << 32) | lo);
@@ -641,6 +645,10 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
 
         qprev = qcur;
         IFL_STAMP(6); // bookkeeping
+#ifdef IFL_STAMPS
+        st_mask[MASK] += st_last - st_t0;
+        st_cnt[MASK] += 1;
+#endif
     };
 
     // A tile's window runs from two steps before its first pixel (the dh=2 fragments and the early pushes) to
@@ -669,6 +677,11 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
 #ifdef IFL_STAMPS
     if (g_stamps && b == 0 && lane == 0)
         for (int k = 0; k < 8; ++k) g_stamps[wave * 8 + k] = st_acc[k];
+    if (g_stamps && b == 0 && lane == 0 && wave == 0)
+        for (int k = 0; k < 4; ++k) {
+            g_stamps[64 + k] = st_mask[k];
+            g_stamps[68 + k] = st_cnt[k];
+        }
 #endif
     // Split fp16 cannot hold |r| >= 65504 (a badly conditioned operator grows r along the sweep): such an
     // image is redone here, by the same workgroup, in exact fp32 from the fp32 copy of the same folded

@@ -7,7 +7,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "inverse-flow_amd")); sys.path.insert(0, ROOT)
 import torch
-buf = torch.zeros(8 * 8, dtype=torch.int64, device="cuda")
+buf = torch.zeros(8 * 8 + 8, dtype=torch.int64, device="cuda")
 os.environ["IFL_STAMPS"] = str(buf.data_ptr())
 import invflow_hip as H
 from bench import ref_init_weight, B, C, HH, WW
@@ -17,10 +17,15 @@ x = torch.randn(B, C, HH, WW, device="cuda"); z = torch.empty_like(x)
 for _ in range(3):
     H.inverse(x, w, out=z)
 torch.cuda.synchronize()
-t = buf.cpu().view(8, 8)
+full = buf.cpu()
+t = full[:64].view(8, 8)
 names = ["dma", "wait+bar", "reads+lead", "crit", "epilogue", "trail", "stores", "loop"]
 for wv in range(8):
     r = t[wv].tolist()
     if sum(r) == 0:
         continue
     print("wave", wv, {names[k]: r[k] for k in range(8)}, "total", sum(r))
+for k, name in enumerate(["no tile", "tile 0", "tile 1", "both tiles"]):
+    c = int(full[68 + k]); tot = int(full[64 + k])
+    if c:
+        print("steps with", name, ":", c, "steps,", tot // c, "cycles each")

@@ -163,12 +163,26 @@ def main():
         avg_s = ms / max(n, 1) * 1e-3
         flops, nbytes = algorithmic(dom, B)
         achieved = flops / avg_s / 1e12
+        # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process,
+        # so the figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/), corrected
+        # as MI355X_MICROARCH.md prescribes.  None when the committed counters are for another kernel / missing.
+        traffic, traffic_src = None, None
+        try:
+            cj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_final_scan_hbm_counters.json")
+            with open(cj) as f:
+                pc = json.load(f)
+            if dom == "scan" and world == 1:
+                traffic = (pc["fetch_size_kib"] * pc["fetch_correction"] + pc["write_size_kib"]) * 1024.0
+                traffic_src = "profiles/r01_final_scan_hbm_counters.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = {
             # the path is a dense CxC contraction (166 flop/B): MFMA-bound.  achieved = ALGORITHMIC flops
             #  / measured launch time; the kernels issue 3 f16 MFMAs per algorithmic product
             # (split fp16, fp32 accumulate), so the peak is the dense f16 MFMA peak.
             "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": None,
+            "unit": "TFLOP/s", "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes": nbytes,
             "issued_tflops": 3.0 * achieved, "frac_issued": 3.0 * achieved / MFMA_F16_PEAK_TFLOPS,
             "frac_vs_f32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS,
             "avg_launch_us": avg_s * 1e6, "launches": n,

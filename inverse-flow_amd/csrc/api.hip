@@ -84,10 +84,10 @@ static int check_shape(const char *fn, int B, int C, int H, int W, int KH, int K
     return IFL_OK;
 }
 
-static size_t fold_bytes(int B, int C, int H, int W, int KH, int KW)
+static size_t fold_bytes(int B, int C, int KH, int KW)
 {
     return align_up((size_t)C * C * sizeof(double), 256) + 2 * align_up((size_t)KH * KW * C * C * sizeof(float), 256) +
-           align_up(((size_t)B + 1) * sizeof(int), 256) + align_up((size_t)C * H * W * sizeof(float), 256) + 1024;
+           align_up(((size_t)B + 1) * sizeof(int), 256) + 1024;
 }
 
 // Forward -> backward side channel ("carry", caller-owned, ifl_carry_bytes): the folded + packed weights of
@@ -131,7 +131,6 @@ static int run_scan(const float *x, const float *w, float *z, const Geom &g, int
     float *wf = cv.take<float>((size_t)g.KH * g.KW * g.C * g.C); // folded taps (fp32) or packed fp16 hi/lo fragments
     float *wf2 = cv.take<float>((size_t)g.KH * g.KW * g.C * g.C); // fp32 copy of the folded taps (in-kernel fp32 redo)
     int *ovf = cv.take<int>((size_t)g.B + 1);                    // per-image overflow flags of the MFMA scan
-    float *sink = cv.take<float>((size_t)g.C * g.H * g.W);       // one image of scratch: sink of the MFMA scan's placeholder stores
     if (!cv.ok()) IFL_FAIL(IFL_EWORKSPACE, "workspace too small: need %zu bytes, have %zu", cv.off, cv.cap);
     int rc;
     if (amax_valid) *amax_valid = false;
@@ -161,7 +160,7 @@ static int run_scan(const float *x, const float *w, float *z, const Geom &g, int
         if (amax_valid) *amax_valid = amax != nullptr;
         // (an image whose r leaves the fp16 range is redone in exact fp32 inside the same launch)
         ProfScope ps(IFL_PROF_SCAN, s);
-        return launch_scan_mfma(x, pack, z, g, rh, rw, ovf, sink, pack32, amax, s);
+        return launch_scan_mfma(x, pack, z, g, rh, rw, ovf, pack32, amax, s);
     }
     {
         ProfScope ps(IFL_PROF_FOLD, s);
@@ -228,12 +227,12 @@ size_t ifl_workspace_bytes(int op, int B, int C, int H, int W, int KH, int KW, u
     switch (op) {
     case IFL_OP_INVERSE:
     case IFL_OP_DY:
-        return fold_bytes(B, C, H, W, KH, KW);
+        return fold_bytes(B, C, KH, KW);
     case IFL_OP_FORWARD:
         return wbytes;
     case IFL_OP_BACKWARD:
         // fold + (dx when the caller passes none) + (A z and mixed gradient for the recon term) + dW partials
-        return fold_bytes(B, C, H, W, KH, KW) + wbytes + 3 * n + wgrad_mfma_workspace_bytes(B, C, H, KH, KW) + 512;
+        return fold_bytes(B, C, KH, KW) + wbytes + 3 * n + wgrad_mfma_workspace_bytes(B, C, H, KH, KW) + 512;
     case IFL_OP_DW:
         return wgrad_mfma_workspace_bytes(B, C, H, KH, KW) + 512;
     default:

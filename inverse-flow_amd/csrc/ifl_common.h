@@ -73,10 +73,8 @@ size_t scan_mfma_pack_bytes(const Geom &g);
 int launch_foldpack_mfma(const float *w, void *out0, float *wf0, void *out1, float *wf1, const Geom &g, int transposed,
                          int ndir, unsigned *zero0, unsigned *zero1, hipStream_t s);
 // amax: optional device word that receives max|z| (atomicMax of float bits; must be cleared beforehand)
-// sink: one image (C*H*W floats) of scratch shared by all workgroups: every step issues a fixed number of stores,
-// those without a finished quad land here
 int launch_scan_mfma(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, int *flags,
-                     float *sink, const float *wf32, unsigned *amax, hipStream_t s);
+                     const float *wf32, unsigned *amax, hipStream_t s);
 
 // ---- MFMA weight gradient (wgrad_mfma.hip): C in {32,64}, W in {16,32}, K in {2x2,3x3}, corner pads ----
 bool wgrad_mfma_supported(int B, int C, int H, int W, int KH, int KW, int pt, int pl, const void *gz, const void *x);

@@ -126,7 +126,7 @@ __device__ __forceinline__ void lgkm_wait_n(int n)
 }
 
 // "all but the N youngest vector-memory operations of this wave are complete", LDS drained, then the workgroup
-// barrier.  N is exact and constant: every step issues the same number of DMAs and stores (see the step body).
+// barrier.  N is a constant (see the step body): an immediate, no dispatch on a run-time count.
 template <int N> __device__ __forceinline__ void wait_vm_then_barrier()
 {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
@@ -154,7 +154,6 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
                                                                     float *__restrict__ zout,
                                                                     const half8 *__restrict__ apack, int H, int W,
                                                                     int rh, int rw, int *__restrict__ flags,
-                                                                    float *__restrict__ sink,
                                                                     const float *__restrict__ wf32, Geom geom,
                                                                     unsigned *__restrict__ amax)
 {
@@ -225,7 +224,7 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
     const int ro_hb = 4 * (wave + Cfg::NWAVES * ro_i); // first row of the operation's row class
     const int ro_ko = ro_dma ? 3 : -5;                 // first column of the quad = d + ko - h (rows h = d-1 mod 4 are due)
     const unsigned long long ro_base = ro_dma ? (unsigned long long)xg : (unsigned long long)zg;
-    const unsigned long long ro_bad = ro_dma ? (unsigned long long)xg : (unsigned long long)sink; // no quad due
+    const unsigned long long ro_bad = ro_dma ? (unsigned long long)xg : (unsigned long long)zg;   // no quad due
     const int ro_lds = ro_dma ? (int)ldsbase + Cfg::OFF_XS : (int)ldsbase + Cfg::OFF_ZQ;
     // byte offset of the quad (row hr, columns wq..wq+3) in a stored channel plane = gbase + hr*grow + wq*gcol
     const int grow = rh ? -4 * W : 4 * W, gcol = rw ? -4 : 4;
@@ -310,10 +309,13 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
             return (char *)(((unsigned long long)hi << 32) | lo);
         };
 
-        // The quads this wave DMA'd three steps ago must have landed before anyone reads them below: younger
-        // than those are exactly the G stores and G DMAs of each of the steps d-2 and d-1 (a step issues its
-        // stores first).  Then the barrier: r of diagonal d-1 and the z staged in step d-1 are complete in LDS.
-        wait_vm_then_barrier<4 * G>();
+        // The quads this wave DMA'd three steps ago must have landed before anyone reads them below.  Younger
+        // vector-memory operations: the G DMAs of each of the steps d-2 and d-1 (always issued) and up to G stores
+        // per step (masked off when no quad is due).  "All but the 2G youngest complete" therefore always covers
+        // the DMA of step d-3 -- with stores in flight it also asks for a DMA that is two steps old, which has
+        // landed long ago -- and never waits for a store of the previous step (a store takes ~2 us to retire).
+        // Then the barrier: r of diagonal d-1 and the z staged in step d-1 are complete in LDS.
+        wait_vm_then_barrier<2 * G>();
         IFL_STAMP(1); // wait + barrier
 
         // in-row staging offset of this step's column w = d - h: the same for all tiles (rows 16 apart)
@@ -424,16 +426,26 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
                 }
         };
         // ---- chunk: store role ----------------------------------------------------------------------------
-        // Every step issues exactly G stores, so that the vector-memory counter can be waited on with a constant:
-        // a row without a finished quad stores its (meaningless) staging read to the workgroup's sink instead.
+        // A row without a finished quad issues its store with all lanes masked off (EXEC = 0, no branch: a branch
+        // would split the block the MFMAs are woven into).  Whether such a store ticks the vector-memory counter
+        // does not matter: the wait before the barrier counts the DMAs only (see there).
         auto chunk_store = [&]() {
             lgkm_wait_n(NYOUNG); // the staged quads have landed (they are the oldest requests)
 #pragma unroll
             for (int i = 0; i < G; ++i) {
-                char *dstp = ro_ptr(G + i); // wave-uniform: the quad's place in z, or the sink
+                char *dstp = ro_ptr(G + i); // wave-uniform: the quad's place in z
                 const unsigned okm = (unsigned)__builtin_amdgcn_readlane(ro_okm, G + i);
+                const unsigned long long em = ((unsigned long long)okm << 32) | okm;
+                unsigned long long saved;
                 if (C == 64 || lane < C) {
-                    *(floatx4_ *)(dstp + voff) = sv[i];
+                    asm volatile("s_mov_b64 %0, exec\n\t"
+                                 "s_and_b64 exec, exec, %1\n\t"
+                                 "global_store_dwordx4 %2, %3, %4\n\t"
+                                 "s_mov_b64 exec, %0\n\t"
+                                 "s_nop 0"
+                                 : "=&s"(saved)
+                                 : "s"(em), "v"(voff), "v"(sv[i]), "s"(dstp)
+                                 : "memory", "scc");
                     const float m = fmaxf(fmaxf(fabsf(sv[i][0]), fabsf(sv[i][1])), fmaxf(fabsf(sv[i][2]), fabsf(sv[i][3])));
                     zmax = fmaxf(zmax, __uint_as_float(__float_as_uint(m) & okm));
                 }
@@ -889,7 +901,7 @@ int launch_foldpack_mfma(const float *w, void *out0, float *wf0, void *out1, flo
 }
 
 template <int C, int KH, int KW, int NTILE>
-static int launch_one(const float *x, float *z, const void *apack, const Geom &g, int rh, int rw, int *flags, float *sink,
+static int launch_one(const float *x, float *z, const void *apack, const Geom &g, int rh, int rw, int *flags,
                       const float *wf32, unsigned *amax, hipStream_t s)
 {
     using Cfg = ScanCfg<C, KH, KW, NTILE>;
@@ -909,17 +921,17 @@ static int launch_one(const float *x, float *z, const void *apack, const Geom &g
     }
 #endif
     hipLaunchKernelGGL((k_scan_mfma<C, KH, KW, NTILE>), dim3(g.B), dim3(Cfg::THREADS), Cfg::LDSB, s, x, z,
-                       (const half8 *)apack, g.H, g.W, rh, rw, flags, sink, wf32, g, amax);
+                       (const half8 *)apack, g.H, g.W, rh, rw, flags, wf32, g, amax);
     IFL_HIP(hipGetLastError());
     return IFL_OK;
 }
 
 int launch_scan_mfma(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, int *flags,
-                     float *sink, const float *wf32, unsigned *amax, hipStream_t s)
+                     const float *wf32, unsigned *amax, hipStream_t s)
 {
     const int nt = g.H <= 16 ? 1 : 2;
 #define IFL_CASE(CC, KK, NN) \
-    if (g.C == CC && g.KH == KK && g.KW == KK && nt == NN) return launch_one<CC, KK, KK, NN>(x, z, apack, g, rh, rw, flags, sink, wf32, amax, s);
+    if (g.C == CC && g.KH == KK && g.KW == KK && nt == NN) return launch_one<CC, KK, KK, NN>(x, z, apack, g, rh, rw, flags, wf32, amax, s);
     IFL_CASE(64, 3, 1)
     IFL_CASE(64, 3, 2)
     IFL_CASE(32, 3, 1)

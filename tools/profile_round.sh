@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round profile on the GPU box: bench line, rocprofv3 kernel stats, and the two HBM counter passes
+# (separate --pmc runs, as MI355X_MICROARCH.md prescribes).  Outputs under gpurun_out/prof_<tag>/.
+set -e
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+python3 $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
+echo "bench done"
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-events > $OUT/stats.log 2>&1
+echo "stats done"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o fetch -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > $OUT/pmc_fetch.log 2>&1
+echo "fetch done"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o write -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > $OUT/pmc_write.log 2>&1
+echo "write done"
+find $OUT -name "*.csv" | head -20

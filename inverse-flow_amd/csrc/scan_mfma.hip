@@ -11,22 +11,28 @@
 // diagonal h+w; every source (h-dh, w-dw) is on an earlier diagonal: solve_mc.py:88-114 in diagonal
 // order, cf. solve_parallel, solve_mc.py:8-50).
 //
-// LDS (~151 KB at C=64, 32 rows):
-//   ring   last KH+KW-1 diagonals of r as split fp16 (hi, lo*2^11), [slot][row block][plane][row%16]
+// Push form.  A step d reads the newest diagonal r_{d-1} from LDS once (three row-shifted fragment sets per
+// tile) and pushes it through every tap into the rolling accumulator of the diagonal it lands on (d, d+1,
+// d+2); only the taps (0,1) and (1,0) are on the dependent chain, the other MFMAs of the step have their
+// operands before or right after the barrier.
+//
+// LDS (~156 KB at C=64, 32 rows):
+//   ring   the last 2 diagonals of r as split fp16 (hi, lo*2^11), [slot][row block][plane][row%16]
 //          16-byte pieces, plane = (k-step, hi/lo, k-group): a lane's MFMA B fragment is one
 //          ds_read_b128 and the 16 lanes of every hardware lane group hit 16 different 4-bank
 //          columns (conflict-free; the naive [row][channel] layout measured 52 % conflict cycles).
-//          Sources above the image read a zero block, pixels left of it are never written and stay
-//          zero: exactly the TL zero padding.
-//   xs     x quads [row][quad parity][channel], filled by LDS-DMA (global_load_lds_dwordx4: no VGPR
+//          Row block 0 of a slot is always zero (sources above the image), pixels left of the image are
+//          never written and stay zero: exactly the TL zero padding.
+//   xs     x quads [row][quad parity][channel][4], filled by LDS-DMA (global_load_lds_dwordx4: no VGPR
 //          destination, nothing for the compiler to track) three steps before their first use.
-//   zring  last 5 diagonals of z (fp32) [slot][row][channel]; a row's quad is stored to NCHW with one
-//          global_store_dwordx4 per channel once its four diagonals are in.
+//   zq     z quads in the same layout; a row's quad is stored to NCHW with one 16-byte store per channel
+//          the step after its fourth column was staged.
+//   dump   where lanes outside the image write their r (branch-free epilogue).
 // Both global streams move 16-byte aligned quads of one (channel, row) line; lane = channel.
 //
-// The only vector-memory operations of a wave are its own DMAs and stores, whose numbers per step are
-// known exactly, so the wait before each barrier is an exact s_waitcnt vmcnt(n): "the DMA issued three
-// steps ago has landed", never "everything, including the stores I just issued".
+// The only vector-memory operations of a wave are its own DMAs (a fixed number per step) and stores, so the
+// wait before each barrier is the immediate s_waitcnt vmcnt(2G): "the DMA issued three steps ago has
+// landed", never "everything, including the stores I just issued".
 //
 // Arithmetic: split-fp16 MFMA with fp32 accumulation.  a*b ~= ah*bh + (ah*bl' + al'*bh) 2^-11 with
 // ah = fp16(a), al' = fp16((a-ah) 2^11): three v_mfma_f32_16x16x32_f16 per 32-deep k-step, the
@@ -54,7 +60,7 @@ template <int C, int KH, int KW, int NTILE> struct ScanCfg {
     static constexpr int NT = KH * KW;     // taps incl. the diagonal one
     static constexpr int NS = NT;          // A slots: NT-1 folded taps + 1 post matrix (L^-1)
     static constexpr int R = 2;            // r-ring depth: the diagonal being written and the previous one (push form)
-    static constexpr int NACC = 3;         // rolling accumulators: diagonals d, d+1, d+2 (rotated by register moves each step)
+    static constexpr int NACC = 3;         // rolling accumulators: diagonals d, d+1, d+2
     static_assert(KH + KW - 2 <= 4 && KH <= 3, "push scan: taps reach at most 4 diagonals ahead, 2 rows up");
     static constexpr int NPL = NQ * 8;     // planes per row block: (k-step, hi/lo, k-group)
     static constexpr int RBB = NPL * 256;  // bytes of one row block (16 rows x NPL planes x 16 B)
@@ -66,7 +72,7 @@ template <int C, int KH, int KW, int NTILE> struct ScanCfg {
     static constexpr int LDSB = OFF_DUMP + 4 * 256 + 64 * NWAVES * 8; // dump: where lanes outside the image write their r (branch-free epilogue)
     static constexpr int THREADS = 64 * NWAVES;
     static constexpr int ROWS_PER_ITER = 4 * NTILE; // rows that start/finish a quad each step
-    static constexpr int G = ROWS_PER_ITER / NWAVES; // ... per wave: DMA (and at most as many store) instructions
+    static constexpr int G = ROWS_PER_ITER / NWAVES; // ... per wave: G DMAs and G (possibly masked) stores per step
     static_assert(ROWS_PER_ITER % NWAVES == 0, "rows per step must split evenly over the waves");
     static_assert(C <= 64, "one DMA / store instruction covers one image row of all channels (lane = channel)");
     static_assert(KH <= 16, "a source row is at most one row block up");

@@ -130,7 +130,7 @@ int ifl_dw_f32(const float *z, const float *dx, float *dw, int B, int C, int H, 
 
 /* z = conv2d(x, w) + bias  (bias may be NULL) -- F.conv2d at inf/layers/selfnorm.py:43. */
 int ifl_conv2d_f32(const float *x, const float *w, const float *bias, float *z, int B, int Ci, int Co, int H,
-                   int W, int KH, int KW, int ph, int pw, ifl_stream_t stream);
+                   int W, int KH, int KW, int ph, int pw, void *ws, size_t ws_bytes, ifl_stream_t stream);
 
 /* dw = cudnn_convolution_backward_weight(gz, x) -- inf/utils/convbackward/conv2d_backward.cpp:7-28. */
 int ifl_conv2d_wgrad_f32(const float *gz, const float *x, float *dw, int B, int Ci, int Co, int H, int W,
@@ -140,7 +140,7 @@ int ifl_conv2d_wgrad_f32(const float *gz, const float *x, float *dw, int B, int 
 int ifl_conv2d_igrad_f32(const float *gz, const float *w, float *dx, int B, int Ci, int Co, int H, int W,
                          int KH, int KW, int ph, int pw, void *ws, size_t ws_bytes, ifl_stream_t stream);
 
-/* scratch for the two calls above */
+/* scratch for the three calls above (ifl_conv2d_f32 also runs without: ws = NULL selects the direct kernel) */
 size_t ifl_conv2d_workspace_bytes(int B, int Ci, int Co, int H, int W, int KH, int KW, int ph, int pw);
 
 #ifdef __cplusplus

@@ -90,6 +90,20 @@ static size_t fold_bytes(int B, int C, int KH, int KW)
            align_up(((size_t)B + 1) * sizeof(int), 256) + 1024;
 }
 
+// out = conv(in, w) + bias, same-size or general: the MFMA kernel where it applies (needs `pack` bytes of
+// conv_pack_bytes), the direct kernel otherwise
+static size_t conv_pack_bytes(int Ci, int Co, int KH, int KW)
+{
+    return Ci == Co ? align_up(conv_mfma_pack_bytes(Ci, KH, KW), 256) + 256 : 0;
+}
+static int run_conv(const float *in, const float *w, const float *bias, float *out, int B, int Ci, int Co, int H, int W,
+                    int OH, int OW, int KH, int KW, int pt, int pl, void *pack, hipStream_t s)
+{
+    if (pack && conv_mfma_supported(Ci, Co, H, W, OH, OW, KH, KW, pt, pl))
+        return launch_conv_mfma(in, w, bias, out, pack, B, Ci, H, W, KH, KW, pt, pl, s);
+    return launch_conv_direct(in, w, bias, out, B, Ci, Co, H, W, OH, OW, KH, KW, pt, pl, s);
+}
+
 // Forward -> backward side channel ("carry", caller-owned, ifl_carry_bytes): the folded + packed weights of
 // the adjoint, produced by the forward call's single fold launch, and two words collecting max|z| / max|dx|
 // from the scans (the weight-gradient kernel's power-of-two prescale), so that the backward needs neither
@@ -223,7 +237,7 @@ size_t ifl_workspace_bytes(int op, int B, int C, int H, int W, int KH, int KW, u
     (void)flags;
     if (B < 0 || C < 1 || H < 1 || W < 1 || KH < 1 || KW < 1) return 0;
     const size_t n = align_up((size_t)B * C * H * W * sizeof(float), 256) + 256;
-    const size_t wbytes = align_up((size_t)KH * KW * C * C * sizeof(float), 256) + 256;
+    const size_t wbytes = align_up((size_t)KH * KW * C * C * sizeof(float), 256) + 256 + conv_pack_bytes(C, C, KH, KW);
     switch (op) {
     case IFL_OP_INVERSE:
     case IFL_OP_DY:
@@ -279,13 +293,16 @@ int ifl_forward_f32(const float *z, const float *w, float *xhat, float *logdet, 
     Geom g = make_geom(B, C, H, W, KH, KW, order, flags);
     Carver cv(ws, ws_bytes);
     float *weff = cv.take<float>((size_t)KH * KW * C * C);
+    void *pack = cv.take<unsigned char>(conv_pack_bytes(C, C, KH, KW));
     if (!cv.ok()) IFL_FAIL(IFL_EWORKSPACE, "ifl_forward_f32: workspace too small: need %zu bytes, have %zu", cv.off, cv.cap);
     if ((rc = launch_effw(w, weff, g, s))) return rc;
     int pt, pl, dkh, dkw;
     order_pads(g, pt, pl, dkh, dkw);
     {
         ProfScope ps(IFL_PROF_CONV, s);
-        if ((rc = launch_conv_direct(z, weff, nullptr, xhat, B, C, C, H, W, H, W, KH, KW, pt, pl, s))) return rc;
+        if ((rc = run_conv(z, weff, nullptr, xhat, B, C, C, H, W, H, W, KH, KW, pt, pl,
+                           (flags & (IFL_FLAG_NO_MFMA | IFL_FLAG_EXACT_F32)) ? nullptr : pack, s)))
+            return rc;
     }
     if (logdet && (rc = launch_logdet(w, logdet, g, s))) return rc;
     return IFL_OK;
@@ -352,6 +369,7 @@ int ifl_backward_f32(const float *gout, const float *z, const float *x, const fl
     const float *gsrc = u;
     if (recon) {
         float *weff = cv.take<float>((size_t)KH * KW * C * C);
+        void *pack = cv.take<unsigned char>(conv_pack_bytes(C, C, KH, KW));
         float *az = cv.take<float>(n);
         float *mix = cv.take<float>(n);
         if (!cv.ok())
@@ -359,7 +377,9 @@ int ifl_backward_f32(const float *gout, const float *z, const float *x, const fl
         int pt, pl, dkh, dkw;
         order_pads(g, pt, pl, dkh, dkw);
         if ((rc = launch_effw(w, weff, g, s))) return rc;
-        if ((rc = launch_conv_direct(z, weff, nullptr, az, B, C, C, H, W, H, W, KH, KW, pt, pl, s))) return rc;
+        if ((rc = run_conv(z, weff, nullptr, az, B, C, C, H, W, H, W, KH, KW, pt, pl,
+                           (flags & (IFL_FLAG_NO_MFMA | IFL_FLAG_EXACT_F32)) ? nullptr : pack, s)))
+            return rc;
         // d/dW of rw*mean_b||x - A z||^2 = -(2 rw / B) sum r (x) shifted z  -> fold into the dW reduction
         if ((rc = launch_recon_mix(u, x, az, mix, 2.0f * recon_weight / (float)B, recon_loss, 1.0f / (float)B, n, s)))
             return rc;
@@ -397,18 +417,22 @@ size_t ifl_conv2d_workspace_bytes(int B, int Ci, int Co, int H, int W, int KH, i
 {
     (void)B; (void)H; (void)W; (void)ph; (void)pw;
     if (Ci < 1 || Co < 1 || KH < 1 || KW < 1) return 0;
-    return align_up((size_t)Ci * Co * KH * KW * sizeof(float), 256) + 256;
+    return align_up((size_t)Ci * Co * KH * KW * sizeof(float), 256) + 256 + conv_pack_bytes(Ci, Co, KH, KW);
 }
 
 int ifl_conv2d_f32(const float *x, const float *w, const float *bias, float *z, int B, int Ci, int Co, int H, int W,
-                   int KH, int KW, int ph, int pw, ifl_stream_t stream)
+                   int KH, int KW, int ph, int pw, void *ws, size_t ws_bytes, ifl_stream_t stream)
 {
     clear_error();
     int rc = check_conv("ifl_conv2d_f32", B, Ci, Co, H, W, KH, KW, ph, pw);
     if (rc) return rc;
     if (!x || !w || !z) IFL_FAIL(IFL_EINVAL, "ifl_conv2d_f32: null tensor pointer");
     const int OH = H + 2 * ph - KH + 1, OW = W + 2 * pw - KW + 1;
-    return launch_conv_direct(x, w, bias, z, B, Ci, Co, H, W, OH, OW, KH, KW, ph, pw, (hipStream_t)stream);
+    // the workspace is optional here: without it (or with too little) the direct kernel runs
+    Carver cv(ws, ws_bytes);
+    void *pack = ws ? cv.take<unsigned char>(conv_pack_bytes(Ci, Co, KH, KW)) : nullptr;
+    if (!cv.ok() || conv_pack_bytes(Ci, Co, KH, KW) == 0) pack = nullptr;
+    return run_conv(x, w, bias, z, B, Ci, Co, H, W, OH, OW, KH, KW, ph, pw, pack, (hipStream_t)stream);
 }
 
 int ifl_conv2d_wgrad_f32(const float *gz, const float *x, float *dw, int B, int Ci, int Co, int H, int W, int KH,
@@ -440,11 +464,13 @@ int ifl_conv2d_igrad_f32(const float *gz, const float *w, float *dx, int B, int 
     hipStream_t s = (hipStream_t)stream;
     Carver cv(ws, ws_bytes);
     float *wt = cv.take<float>((size_t)Ci * Co * KH * KW);
+    void *pack = cv.take<unsigned char>(conv_pack_bytes(Ci, Co, KH, KW));
     if (!cv.ok())
         IFL_FAIL(IFL_EWORKSPACE, "ifl_conv2d_igrad_f32: workspace too small: need %zu bytes, have %zu", cv.off, cv.cap);
     if ((rc = launch_flip_kernel(w, wt, Co, Ci, KH, KW, s))) return rc;
     // dx = conv2d(gz, flip_kernel(w), padding = K-1-p): input (B,Co,OH,OW) -> output (B,Ci,H,W)
-    return launch_conv_direct(gz, wt, nullptr, dx, B, Co, Ci, OH, OW, H, W, KH, KW, KH - 1 - ph, KW - 1 - pw, s);
+    return run_conv(gz, wt, nullptr, dx, B, Co, Ci, OH, OW, H, W, KH, KW, KH - 1 - ph, KW - 1 - pw,
+                    conv_pack_bytes(Ci, Co, KH, KW) ? pack : nullptr, s);
 }
 
 } // extern "C"

@@ -1,0 +1,293 @@
+// Dense same-size convolution on the matrix cores (gfx950, wave64) for the shapes of the hot path:
+//     out[b][co][h][w] = bias[co] + sum_{ci,kh,kw} w[co][ci][kh][kw] * in[b][ci][h-pt+kh][w-pl+kw]     (zero outside)
+// with Ci = Co = C in {32, 64}, K in {2x2, 3x3}, W in {16, 32}, 0 <= pt < KH, 0 <= pl < KW.  It serves
+//   * x^ = A z, the layer's reverse (inv_conv.py:249-267,442-460 -> inv_conv_with_bp.forward,
+//     inv_conv_with_bp_general.cpp:44-53): corner padding, effective weight,
+//   * F.conv2d of SelfNormConv (inf/layers/selfnorm.py:43) and cudnn_convolution_backward_input
+//     (inf/utils/convbackward/conv2d_backward.cpp:32-53; a conv with the flipped kernel).
+// The first-correct direct kernel (conv_general.hip) stays for every other shape.
+//
+// One workgroup = one band of 8 output rows of one image; one wave = 16 output channels (one wave per SIMD).
+// The band's input (8 + KH-1 rows, W + KW-1 columns, zero halo) is staged once in LDS as split fp16
+// (hi = fp16(v), lo' = fp16((v-hi) 2^11)) in the MFMA B-fragment layout [plane][pixel], plane = (k-step, hi/lo,
+// k-group of 8 channels), one 16-byte piece per pixel: the fragment of ANY tap is then a plain ds_read_b128 at
+// a pixel offset -- no im2col, no per-tap copies.  The weights live in AGPRs as split-fp16 A fragments (packed
+// by k_convpack).  Per 16-pixel tile and tap three v_mfma_f32_16x16x32_f16 per 32-deep k-step, fp32 accumulate
+// (the arithmetic of the scan); two tiles are in flight so that dependent MFMAs are 2+ apart,
+// and the fragments of the next tap are requested one per MFMA while the current tap multiplies.
+// A band whose input leaves the fp16 range (|v| >= 6e4) is redone in plain fp32 by the same workgroup.
+#include <type_traits>
+#include <utility>
+
+#include "ifl_common.h"
+#include "mfma_util.h"
+
+namespace ifl {
+
+template <int... S, class Fn> __device__ __forceinline__ void for_seq(std::integer_sequence<int, S...>, Fn &&f)
+{
+    (f(std::integral_constant<int, S>{}), ...);
+}
+
+template <int C, int KH, int KW, int WT> struct ConvCfg {
+    static constexpr int NW = C / 16;  // waves = 16-channel output groups
+    static constexpr int NQ = C / 32;  // 32-deep k-steps per tap
+    static constexpr int NT = KH * KW;
+    static constexpr int RB = 8;                            // output rows per band
+    static constexpr int PR = RB + KH - 1, PC = WT + KW - 1; // staged rows / columns (halo included)
+    static constexpr int PP = PR * PC;                      // staged pixels
+    static constexpr int PB = PP * 16;                      // bytes of one plane
+    static constexpr int NPL = NQ * 8;                      // planes: (k-step, hi/lo, k-group)
+    static constexpr int LDSB = NPL * PB;
+    static constexpr int THREADS = 64 * NW;
+    static constexpr int TPR = WT / 16;      // 16-pixel tiles per row
+    static constexpr int NP = RB * TPR / 2;  // tile pairs per band
+    static_assert(WT % 16 == 0 && (RB * TPR) % 2 == 0 && NP % 2 == 0, "tiles come in pairs, pairs in pairs");
+    static_assert(LDSB <= 160 * 1024, "band staging must fit the CU's LDS");
+    static_assert(4 * PB + (KH * PC + KW) * 16 < 65536, "fragment offsets must fit the ds offset field");
+};
+
+// apack[wv][t][q][hl][lane][8] (fp16): lane = m + 16 gk holds row co = 16 wv + m, k = ci = 32 q + 8 gk + j of tap t
+__global__ __launch_bounds__(256) void k_convpack(const float *__restrict__ w, _Float16 *__restrict__ apack, int C, int KH,
+                                                  int KW)
+{
+    const int NT = KH * KW, NQ = C / 32;
+    const size_t total = (size_t)(C / 16) * NT * NQ * 64 * 8;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % 8), lane = (int)((i / 8) % 64);
+        const int q = (int)((i / 512) % NQ), t = (int)((i / (512 * (size_t)NQ)) % NT), wv = (int)(i / (512 * (size_t)NQ * NT));
+        const int co = 16 * wv + (lane & 15), ci = 32 * q + 8 * (lane >> 4) + j;
+        const float v = w[((size_t)co * C + ci) * NT + t];
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)((v - (float)hi) * LO_SCALE);
+        const size_t base = ((((size_t)wv * NT + t) * NQ + q) * 2) * 64 * 8;
+        apack[base + (size_t)lane * 8 + j] = hi;
+        apack[base + (size_t)64 * 8 + (size_t)lane * 8 + j] = lo;
+    }
+}
+
+template <int C, int KH, int KW, int WT>
+__global__ __launch_bounds__(64 * (C / 16)) void k_conv_mfma(const float *__restrict__ in, const half8 *__restrict__ apack,
+                                                              const float *__restrict__ w32,
+                                                              const float *__restrict__ bias, float *__restrict__ out,
+                                                              int H, int pt, int pl)
+{
+    using Cfg = ConvCfg<C, KH, KW, WT>;
+    constexpr int NQ = Cfg::NQ, NT = Cfg::NT, RB = Cfg::RB, PC = Cfg::PC, PP = Cfg::PP, PB = Cfg::PB, TPR = Cfg::TPR,
+                  NP = Cfg::NP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y, h0 = blockIdx.x * RB;
+    const float *inb = in + (size_t)b * C * H * WT;
+    float *outb = out + (size_t)b * C * H * WT;
+
+    // ---- weights -> registers (pinned in the accumulator half of the register file, see scan_mfma.hip) ------------
+    half8 A[NT][NQ][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl) {
+                A[t][q][hl] = apack[((((size_t)wv * NT + t) * NQ + q) * 2 + hl) * 64 + lane];
+                asm volatile("" : "+a"(A[t][q][hl]));
+            }
+
+    // ---- stage the band: item = (k-group of 8 channels, pixel), pixels fastest (coalesced along w) ---------------
+    float vmax = 0.f;
+    for (int it = tid; it < PP * (C / 8); it += Cfg::THREADS) {
+        const int kg = it / PP, p = it % PP;
+        const int rr = p / PC, cc = p % PC;
+        const int ih = h0 - pt + rr, iw = cc - pl;
+        const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < WT;
+        const float *src = inb + ((size_t)(8 * kg) * H + (ok ? ih : 0)) * WT + (ok ? iw : 0);
+        half8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = ok ? src[(size_t)j * H * WT] : 0.f;
+            vmax = fmaxf(vmax, fabsf(v));
+            const _Float16 h16 = (_Float16)v;
+            hi[j] = h16;
+            lo[j] = (_Float16)((v - (float)h16) * LO_SCALE);
+        }
+        const int q = kg / 4, gk = kg % 4;
+        *(half8 *)(lds + ((q * 2 + 0) * 4 + gk) * PB + p * 16) = hi;
+        *(half8 *)(lds + ((q * 2 + 1) * 4 + gk) * PB + p * 16) = lo;
+    }
+    // (also the barrier between staging and use)
+    if (__syncthreads_or(vmax < 6.0e4f ? 0 : 1)) {
+        // the band leaves the fp16 range (or holds a NaN/Inf): plain fp32, straight from memory.  Rare and slow.
+        for (int o = tid; o < C * RB * WT; o += Cfg::THREADS) {
+            const int ow = o % WT, r = (o / WT) % RB, co = o / (WT * RB);
+            const int oh = h0 + r;
+            if (oh >= H) continue;
+            float acc = bias ? bias[co] : 0.f;
+            for (int ci = 0; ci < C; ++ci)
+                for (int kh = 0; kh < KH; ++kh) {
+                    const int ih = oh - pt + kh;
+                    if (ih < 0 || ih >= H) continue;
+                    for (int kw = 0; kw < KW; ++kw) {
+                        const int iw = ow - pl + kw;
+                        if (iw < 0 || iw >= WT) continue;
+                        acc = fmaf(w32[((size_t)co * C + ci) * NT + kh * KW + kw], inb[((size_t)ci * H + ih) * WT + iw], acc);
+                    }
+                }
+            outb[((size_t)co * H + oh) * WT + ow] = acc;
+        }
+        return;
+    }
+
+    // ---- multiply: tile pairs, taps double-buffered ---------------------------------------------------------
+    const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    const unsigned fa_lane = ldsbase + g * PB + n * 16; // this lane's piece of pixel 0 in plane (0, hi, g)
+    const int c0 = 16 * wv + 4 * g;                    // C/D layout: lane (n, g) holds channels c0..c0+3 of pixel n
+    floatx4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = floatx4{bias[c0], bias[c0 + 1], bias[c0 + 2], bias[c0 + 3]};
+
+    // fragments of one tap: [buffer][tile of the pair][k-step][hi/lo].  Small on purpose: a fragment register that
+    // the compiler has to park somewhere else (AGPR spill) right behind the inline-asm read would be copied before
+    // its data has landed.
+    half8 F[2][2][NQ][2];
+    floatx4 ahi[2], amid[2];
+    constexpr int NRD = 2 * NQ * 2; // requests of one tap
+    constexpr int NMF = 2 * NQ * 3; // MFMAs of one tap
+
+    // request number j of tap T_ of pair p, into buffer BUF
+    auto request = [&](auto buf_c, auto tap_c, int p, int j) {
+        constexpr int BUF = decltype(buf_c)::value, TAP = decltype(tap_c)::value;
+        constexpr int OFFT = ((TAP / KW) * PC + (TAP % KW)) * 16; // the tap's pixel offset
+        int c = 0;
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+            const int t = 2 * p + T, r = t / TPR, w0 = 16 * (t % TPR);
+            const unsigned a0 = fa_lane + (r * PC + w0) * 16;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                // plane (q, hl, g): q and the pixel in the address register, hl and the tap in the offset field
+                if (c++ == j) lds_read_b128_o<OFFT>(F[BUF][T][q][0], a0 + q * 8 * PB);
+                if (c++ == j) lds_read_b128_o<4 * PB + OFFT>(F[BUF][T][q][1], a0 + q * 8 * PB);
+            }
+        }
+    };
+    // MFMA number k of tap TAP from buffer BUF (order: per k-step hi.hi, hi.lo of both tiles, then the lo.hi
+    // products); the pair's first tap starts its accumulators from zero
+    auto mfma = [&](auto buf_c, auto tap_c, int k) {
+        constexpr int BUF = decltype(buf_c)::value, TAP = decltype(tap_c)::value;
+        const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+        int c = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int T = 0; T < 2; ++T)
+                if (c++ == k)
+                    ahi[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[TAP][q][0], F[BUF][T][q][0],
+                                                                    (TAP == 0 && q == 0) ? zero : ahi[T], 0, 0, 0);
+#pragma unroll
+            for (int T = 0; T < 2; ++T)
+                if (c++ == k)
+                    amid[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[TAP][q][0], F[BUF][T][q][1],
+                                                                     (TAP == 0 && q == 0) ? zero : amid[T], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int T = 0; T < 2; ++T)
+                if (c++ == k)
+                    amid[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[TAP][q][1], F[BUF][T][q][0], amid[T], 0, 0, 0);
+    };
+    auto epilogue = [&](int p) {
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+            const int t = 2 * p + T, r = t / TPR, w0 = 16 * (t % TPR);
+            const int oh = h0 + r;
+            if (oh < H) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    outb[((size_t)(c0 + e) * H + oh) * WT + w0 + n] = ahi[T][e] + amid[T][e] * LO_INV + bv[e];
+            }
+        }
+    };
+    // Stage S of a block of two tile pairs starting at pair p: tap S mod NT of pair p + S / NT.  Its fragments
+    // (requested during the previous stage) have landed; it multiplies while the next tap's requests go out one per
+    // MFMA (measured: an MFMA hides one ds_read_b128, tools/issue_rate_probe.hip).  Buffers alternate with S.
+    auto block_stage = [&](auto s_c, int p) {
+        constexpr int S = decltype(s_c)::value;
+        constexpr int TAP = S % NT, SN = (S + 1) % (2 * NT), TAPN = SN % NT;
+        using BUF = std::integral_constant<int, S & 1>;
+        using NBUF = std::integral_constant<int, 1 - (S & 1)>;
+        const int pc = p + S / NT;                           // this stage's pair
+        const int pn = S + 1 < 2 * NT ? p + (S + 1) / NT : p + 2; // the next stage's pair
+        const bool more = pn < NP;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < NMF; ++k) {
+            mfma(BUF{}, std::integral_constant<int, TAP>{}, k);
+            // (MFMAs are pure: tie the results to an opaque statement, or they sink below the requests)
+            asm volatile("" : "+a"(ahi[0]), "+a"(ahi[1]), "+a"(amid[0]), "+a"(amid[1]));
+            __builtin_amdgcn_sched_barrier(0);
+            if (k < NRD && more) request(NBUF{}, std::integral_constant<int, TAPN>{}, pn, k);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (TAP == NT - 1) epilogue(pc);
+    };
+
+#pragma unroll
+    for (int j = 0; j < NRD; ++j) request(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0, j);
+    for (int p = 0; p < NP; p += 2) for_seq(std::make_integer_sequence<int, 2 * NT>{}, [&](auto s_c) { block_stage(s_c, p); });
+}
+
+bool conv_mfma_supported(int Ci, int Co, int H, int W, int OH, int OW, int KH, int KW, int pt, int pl)
+{
+    if (Ci != Co || !(Ci == 32 || Ci == 64)) return false;
+    if (!((KH == 3 && KW == 3) || (KH == 2 && KW == 2))) return false;
+    if (!(W == 16 || W == 32) || OH != H || OW != W) return false;
+    if (pt < 0 || pt >= KH || pl < 0 || pl >= KW) return false;
+    return true;
+}
+
+size_t conv_mfma_pack_bytes(int C, int KH, int KW) { return (size_t)KH * KW * C * C * 2 * sizeof(_Float16); }
+
+template <int C, int KH, int KW, int WT>
+static int launch_conv_one(const float *in, const void *apack, const float *w, const float *bias, float *out, int B, int H,
+                           int pt, int pl, hipStream_t s)
+{
+    using Cfg = ConvCfg<C, KH, KW, WT>;
+    static bool attr_done = false; // idempotent attribute, benign race
+    if (!attr_done) {
+        IFL_HIP(hipFuncSetAttribute((const void *)k_conv_mfma<C, KH, KW, WT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    Cfg::LDSB));
+        attr_done = true;
+    }
+    const dim3 grid((H + Cfg::RB - 1) / Cfg::RB, B);
+    hipLaunchKernelGGL((k_conv_mfma<C, KH, KW, WT>), grid, dim3(Cfg::THREADS), Cfg::LDSB, s, in, (const half8 *)apack, w,
+                       bias, out, H, pt, pl);
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+
+// apack: conv_mfma_pack_bytes of workspace; w: (C, C, KH, KW) fp32 (also read by the fp32 redo of a band)
+int launch_conv_mfma(const float *in, const float *w, const float *bias, float *out, void *apack, int B, int C, int H,
+                     int W, int KH, int KW, int pt, int pl, hipStream_t s)
+{
+    if (B == 0) return IFL_OK;
+    const size_t total = (size_t)KH * KW * C * C * 2;
+    hipLaunchKernelGGL(k_convpack, dim3((unsigned)((total / 2 + 255) / 256)), dim3(256), 0, s, w, (_Float16 *)apack, C, KH, KW);
+    IFL_HIP(hipGetLastError());
+#define IFL_CASE(CC, KK, WW) \
+    if (C == CC && KH == KK && W == WW) return launch_conv_one<CC, KK, KK, WW>(in, apack, w, bias, out, B, H, pt, pl, s);
+    IFL_CASE(64, 3, 32)
+    IFL_CASE(64, 3, 16)
+    IFL_CASE(32, 3, 32)
+    IFL_CASE(32, 3, 16)
+    IFL_CASE(64, 2, 32)
+    IFL_CASE(64, 2, 16)
+    IFL_CASE(32, 2, 32)
+    IFL_CASE(32, 2, 16)
+#undef IFL_CASE
+    IFL_FAIL(IFL_EUNSUPPORTED, "launch_conv_mfma: no instantiation for C=%d K=%d W=%d", C, KH, W);
+}
+
+} // namespace ifl

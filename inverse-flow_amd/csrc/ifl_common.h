@@ -86,6 +86,13 @@ int launch_wgrad_mfma(const float *gz, const float *x, float *dw, void *ws, int 
                       int pt, int pl, float scale, int mask_mode, int mkh, int mkw, const unsigned *amax_gz,
                       const unsigned *amax_x, hipStream_t s);
 
+// ---- MFMA dense same-size convolution (conv_mfma.hip): Ci = Co in {32,64}, K in {2x2,3x3}, W in {16,32} --------
+bool conv_mfma_supported(int Ci, int Co, int H, int W, int OH, int OW, int KH, int KW, int pt, int pl);
+size_t conv_mfma_pack_bytes(int C, int KH, int KW);
+// apack: conv_mfma_pack_bytes of workspace (packed by the launch); w: (C, C, KH, KW) fp32
+int launch_conv_mfma(const float *in, const float *w, const float *bias, float *out, void *apack, int B, int C, int H,
+                     int W, int KH, int KW, int pt, int pl, hipStream_t s);
+
 // ---- general (any C, any K) VALU kernels (scan_general.hip, conv_general.hip) ----------------
 size_t scan_general_lds_bytes(const Geom &g);
 // z = scan(x) with folded taps wf; pixel reflection (rh, rw) applied to both x and z addressing.

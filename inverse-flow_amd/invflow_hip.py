@@ -35,7 +35,7 @@ SIGNATURES = {
     "ifl_forward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "ifl_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp]),
     "ifl_dw_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
-    "ifl_conv2d_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ifl_conv2d_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ifl_conv2d_wgrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ifl_conv2d_igrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ifl_conv2d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
@@ -264,9 +264,12 @@ def conv2d(x, w, bias=None, padding=(0, 0)):
     B, Ci, Co, H, W, KH, KW, ph, pw = _conv_dims(x, w.shape, padding)
     dev = _same_device(x, w, bias)
     out = torch.empty(B, Co, H + 2 * ph - KH + 1, W + 2 * pw - KW + 1, dtype=torch.float32, device=dev)
+    L = lib()
     with torch.cuda.device(dev):
-        rc = lib().ifl_conv2d_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), B, Ci, Co, H, W, KH, KW, ph, pw,
-                                  torch.cuda.current_stream().cuda_stream)
+        nb = L.ifl_conv2d_workspace_bytes(B, Ci, Co, H, W, KH, KW, ph, pw)
+        ws = _ws(nb, dev)
+        rc = L.ifl_conv2d_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), B, Ci, Co, H, W, KH, KW, ph, pw, _ptr(ws), nb,
+                              torch.cuda.current_stream().cuda_stream)
     _check(rc, "ifl_conv2d_f32")
     return out
 

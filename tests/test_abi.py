@@ -64,7 +64,7 @@ def test_argument_validation_without_gpu(H):
     # null tensors with a non-empty batch
     rc = L.ifl_inverse_f32(None, None, None, 1, 4, 5, 5, 3, 3, 0, 0, None, 0, None, None)
     assert rc == -1 and b"null tensor" in L.ifl_last_error()
-    rc = L.ifl_conv2d_f32(None, None, None, None, 1, 4, 4, 2, 2, 3, 3, 0, 0, None)
+    rc = L.ifl_conv2d_f32(None, None, None, None, 1, 4, 4, 2, 2, 3, 3, 0, 0, None, 0, None)
     assert rc == -1 and b"kernel larger" in L.ifl_last_error()
 
 

@@ -117,6 +117,11 @@ CASES = [
     (2, 5, 6, 6, 1, 1, "0.2", "TL", 0),  # 1x1 kernel: pure in-pixel triangular solve
     (1, 256, 4, 4, 3, 3, "0.01", "TL", 0),  # config 5 channel count
     (2, 7, 33, 20, 3, 3, "0.03", "TL", 0),  # ragged sizes
+    (3, 64, 32, 32, 3, 3, "refinit", "TR", 0),  # MFMA scan + MFMA conv (x^ = A z), every order and tile shape
+    (3, 64, 20, 32, 3, 3, "0.02", "BL", 0),     # rows not a multiple of the conv's 8-row band / the scan's tiles
+    (2, 64, 16, 16, 2, 2, "0.05", "BR", 0),
+    (2, 32, 32, 16, 2, 2, "0.05", "TR", 1),
+    (2, 32, 8, 32, 3, 3, "0.05", "TL", 1),
 ]
 
 
@@ -144,6 +149,42 @@ def test_against_oracle(H, oracle, case):
     assert rel_err(host(dw), dw_o) < TOL
     m = oracle.mask(C, KH, KW, diag, order)
     assert np.all(host(dw)[m == 0] == 0)
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 32, 32, 3, 1), (2, 64, 12, 16, 3, 1), (2, 32, 16, 32, 3, 1), (2, 32, 32, 16, 3, 1),
+                                   (2, 64, 16, 16, 3, 0), (2, 48, 16, 16, 3, 1)],
+                         ids=lambda s_: "b%dc%d_%dx%d_k%d_p%d" % s_)
+def test_dense_conv_pieces(H, oracle, shape):
+    """SelfNormConv's dense contractions (selfnorm.py:42-82): conv2d, backward_input, backward_weight through the C ABI
+    against the oracle; same-size shapes with C in {32,64} run on the MFMA conv kernel, the others on the direct one."""
+    B, C, Hh, Ww, K, p = shape
+    rng = np.random.default_rng(7 + B + C + Hh)
+    x = rng.standard_normal((B, C, Hh, Ww)).astype(np.float32)
+    w = (0.05 * rng.standard_normal((C, C, K, K))).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    y_o = oracle.conv2d(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), (p, p), nthreads=8)
+    y = H.conv2d(dev(x), dev(w), dev(b), (p, p))
+    assert rel_err(host(y), y_o) < TOL
+    gz = rng.standard_normal(y_o.shape).astype(np.float32)
+    gx_o = oracle.conv2d_igrad(gz.astype(np.float64), w.astype(np.float64), x.shape, (p, p), nthreads=8)
+    gx = H.conv2d_igrad(dev(gz), dev(w), x.shape, (p, p))
+    assert rel_err(host(gx), gx_o) < TOL
+    gw_o = oracle.conv2d_wgrad(gz.astype(np.float64), x.astype(np.float64), w.shape, (p, p), nthreads=8)
+    gw = H.conv2d_wgrad(dev(gz), dev(x), w.shape, (p, p))
+    assert rel_err(host(gw), gw_o) < TOL
+
+
+def test_dense_conv_fp16_range(H, oracle):
+    """A band whose input leaves the fp16 range is redone in fp32 by the same workgroup (conv_mfma.hip): finite,
+    fp32-accurate results, and the other bands keep their split-fp16 results."""
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((2, 64, 32, 32)).astype(np.float32)
+    x[1, 5, 13, 7] = 3.0e5  # one pixel beyond fp16: its band (rows 8..15 of image 1) takes the fp32 route
+    w = (0.05 * rng.standard_normal((64, 64, 3, 3))).astype(np.float32)
+    y_o = oracle.conv2d(x.astype(np.float64), w.astype(np.float64), None, (1, 1), nthreads=8)
+    y = host(H.conv2d(dev(x), dev(w), None, (1, 1)))
+    assert np.all(np.isfinite(y))
+    assert rel_err(y, y_o) < TOL
 
 
 def test_recon_term(H, oracle):

@@ -147,6 +147,17 @@ def main():
     H.profile_enable(False)
     prof = H.profile_collect()
 
+    # "also report forward + log-det (z -> x^) separately" -- outside the timed region of the metric
+    xh = torch.empty_like(z)
+    for _ in range(3):
+        H.forward(z, w, "TL", args.flags, out=xh, want_logdet=True)
+    torch.cuda.synchronize()
+    tf0 = time.perf_counter()
+    for _ in range(20):
+        H.forward(z, w, "TL", args.flags, out=xh, want_logdet=True)
+    torch.cuda.synchronize()
+    fwd_ms = (time.perf_counter() - tf0) / 20 * 1e3
+
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -200,6 +211,8 @@ def main():
                                    "inverse (x->z) + fused backward (g,z->dx,dW)" + ("; dW all-reduce over RCCL" if world > 1 else ""),
                        "B": B, "C": C, "H": HH, "W": WW, "K": K, "logdet_abs_err": 0.0},
             "roofline": roofline,
+            "forward_logdet": {"ms": fwd_ms, "images_per_s": B / (fwd_ms * 1e-3),
+                               "what": "ifl_forward_f32: z -> x^ = A z and log|det A| (the layer's reverse), per rank, not part of value"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w_host)

@@ -702,33 +702,65 @@ __global__ __launch_bounds__(256) void k_foldpack(const float *__restrict__ w, _
         if (zero0) *zero0 = 0u;
         if (zero1) *zero1 = 0u;
     }
+#ifdef IFL_STAMPS
+    unsigned long long ft[8], fl_ = __builtin_amdgcn_s_memtime();
+    int fk = 0;
+#define IFL_FSTAMP()                                                   \
+    do {                                                               \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            \
+        ft[fk++] = t_ - fl_;                                           \
+        fl_ = t_;                                                      \
+    } while (0)
+#else
+#define IFL_FSTAMP() \
+    do {             \
+    } while (0)
+#endif
     constexpr int NBK = C / 16, XP = C + 1; // XP: fp64 row pitch (conflict-free row- and column-wise)
-    __shared__ float sL[C * C];
+    constexpr int LP = C + 1; // row pitch of L: rows a wave reads together fall into different banks
+    __shared__ float sL[C * LP];
     __shared__ double sX[C * XP];
-    __shared__ double sS[(NBK > 1 ? NBK - 1 : 1) * 256];
-    __shared__ float sW[16 * C];
+    __shared__ __attribute__((aligned(16))) float sW[16 * C];
     const int tid = threadIdx.x;
     const int NT = g.KH * g.KW, RG = C / 16, NQ = C / 32;
     const int s = blockIdx.x / RG, rgrp = blockIdx.x % RG;
 
     // ---- L (effective diagonal tap) and this workgroup's 16 rows of W_t ----------------------------
-    for (int idx = tid; idx < C * C; idx += 256) {
-        const int i = idx / C, k = idx % C;
-        float v = 0.f;
-        if (k < i) v = w[w_index2(i, k, 0, 0, C, g.KH, g.KW, g.flipH, g.flipW)];
-        else if (k == i) v = g.general_diag ? w[w_index2(i, i, 0, 0, C, g.KH, g.KW, g.flipH, g.flipW)] : 1.f;
-        sL[idx] = v;
-    }
-    if (s < NT - 1) {
-        const int t = s + 1, dh = t / g.KW, dw = t % g.KW;
-        for (int idx = tid; idx < 16 * C; idx += 256) {
-            const int cl = idx / C, m = idx % C, c = 16 * rgrp + cl;
-            sW[idx] = transposed ? w[w_index2(m, c, dh, dw, C, g.KH, g.KW, g.flipH, g.flipW)]
-                                 : w[w_index2(c, m, dh, dw, C, g.KH, g.KW, g.flipH, g.flipW)];
+    // All gathers (stride KH*KW floats) are issued before any is used: unconditional loads into registers, the
+    // triangle / unit diagonal applied afterwards (a conditional load per iteration made this phase a chain of
+    // ~20 exposed memory latencies: 15.8k of the kernel's 41k cycles).
+    {
+        constexpr int NL = C * C / 256, NWL = 16 * C / 256;
+        float vl[NL], vw[NWL > 0 ? NWL : 1];
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const int idx = tid + 256 * u, i = idx / C, k = idx % C;
+            vl[u] = w[w_index2(i, k, 0, 0, C, g.KH, g.KW, g.flipH, g.flipW)];
+        }
+        const int t = s < NT - 1 ? s + 1 : 1 % (NT > 1 ? NT : 2), dh = t / g.KW, dw = t % g.KW; // (last slot: a valid tap, unused)
+#pragma unroll
+        for (int u = 0; u < NWL; ++u) {
+            const int idx = tid + 256 * u, cl = idx / C, m = idx % C, c = 16 * rgrp + cl;
+            vw[u] = transposed ? w[w_index2(m, c, NT > 1 ? dh : 0, NT > 1 ? dw : 0, C, g.KH, g.KW, g.flipH, g.flipW)]
+                               : w[w_index2(c, m, NT > 1 ? dh : 0, NT > 1 ? dw : 0, C, g.KH, g.KW, g.flipH, g.flipW)];
+        }
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const int idx = tid + 256 * u, i = idx / C, k = idx % C;
+            sL[i * LP + k] = k < i ? vl[u] : (k == i ? (g.general_diag ? vl[u] : 1.f) : 0.f);
+        }
+        if (s < NT - 1) {
+#pragma unroll
+            for (int u = 0; u < NWL; ++u) {
+                const int idx = tid + 256 * u;
+                sW[(idx % C) * 16 + idx / C] = vw[u]; // [m][row]: a thread's four rows are one 16-byte read
+            }
         }
     }
     for (int idx = tid; idx < C * XP; idx += 256) sX[idx] = 0.0;
     __syncthreads();
+    IFL_FSTAMP(); // 0: loads
 
     // ---- diagonal blocks of L^-1: column j by forward substitution inside its 16x16 block; the column
     //      lives in registers (fully unrolled), L comes from LDS and does not depend on the chain ------
@@ -740,84 +772,91 @@ __global__ __launch_bounds__(256) void k_foldpack(const float *__restrict__ w, _
             double a0 = (ii == jj) ? 1.0 : 0.0, a1 = 0.0;
 #pragma unroll
             for (int kk = 0; kk < 16; kk += 2) {
-                if (kk < ii) a0 -= (double)sL[(r0 + ii) * C + r0 + kk] * (kk >= jj ? col[kk] : 0.0);
-                if (kk + 1 < ii) a1 -= (double)sL[(r0 + ii) * C + r0 + kk + 1] * (kk + 1 >= jj ? col[kk + 1] : 0.0);
+                if (kk < ii) a0 -= (double)sL[(r0 + ii) * LP + r0 + kk] * (kk >= jj ? col[kk] : 0.0);
+                if (kk + 1 < ii) a1 -= (double)sL[(r0 + ii) * LP + r0 + kk + 1] * (kk + 1 >= jj ? col[kk + 1] : 0.0);
             }
-            col[ii] = ii >= jj ? (a0 + a1) / (double)sL[(r0 + ii) * C + r0 + ii] : 0.0;
+            col[ii] = ii >= jj ? (a0 + a1) / (double)sL[(r0 + ii) * LP + r0 + ii] : 0.0;
             sX[(r0 + ii) * XP + j] = col[ii];
         }
     }
     __syncthreads();
+    IFL_FSTAMP(); // 1: diagonal blocks
 
-    // ---- off-diagonal blocks, one block-distance at a time ----------------------------------------
+    // ---- off-diagonal blocks, one block-distance at a time, on the fp64 matrix cores: X_ij = -X_ii (sum_k L_ik X_kj).
+    //      One wave per pair (i, j) of a distance.  v_mfma_f64_16x16x4_f64 layouts (tools/mfma_f64_layout_probe.hip):
+    //      A[i = l%16][k = l/16], B[k = l/16][j = l%16] one double per lane, D[i = 4v + l/16][j = l%16] in register v
+    //      -- so register kc of a result IS the B operand of k-chunk kc of the next product: the inner sum S goes
+    //      straight into the second product without leaving the registers. ----------------------------------------
+    typedef double doublex4 __attribute__((ext_vector_type(4)));
+    const int wvf = tid / 64, lf = tid % 64, li = lf % 16, lk = lf / 16;
     {
-        const int r = tid / 16, cc = tid % 16;
 #pragma unroll 1
         for (int dist = 1; dist < NBK; ++dist) {
             const int npairs = NBK - dist;
-            for (int p = 0; p < npairs; ++p) {
-                const int bi = p + dist, bj = p;
-                const int row = 16 * bi + r, col = 16 * bj + cc;
-                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            const int bi = wvf + dist, bj = wvf;
+            if (wvf < npairs) {
+                doublex4 acc = {0.0, 0.0, 0.0, 0.0};
                 for (int kb = bj; kb < bi; ++kb) {
 #pragma unroll
-                    for (int kk = 0; kk < 16; kk += 4) {
-                        const int k = 16 * kb + kk;
-                        a0 += (double)sL[row * C + k] * sX[k * XP + col];
-                        a1 += (double)sL[row * C + k + 1] * sX[(k + 1) * XP + col];
-                        a2 += (double)sL[row * C + k + 2] * sX[(k + 2) * XP + col];
-                        a3 += (double)sL[row * C + k + 3] * sX[(k + 3) * XP + col];
+                    for (int kc = 0; kc < 4; ++kc) {
+                        const int k = 16 * kb + 4 * kc + lk;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)sL[(16 * bi + li) * LP + k], sX[k * XP + 16 * bj + li], acc, 0, 0, 0);
                     }
                 }
-                sS[p * 256 + tid] = (a0 + a1) + (a2 + a3);
-            }
-            __syncthreads();
-            for (int p = 0; p < npairs; ++p) {
-                const int bi = p + dist, bj = p;
-                const int row = 16 * bi + r, col = 16 * bj + cc;
-                double a0 = 0.0, a1 = 0.0;
+                doublex4 res = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int kk = 0; kk < 16; kk += 2) {
-                    // X_ii is lower triangular: entries with kk > r are exactly zero in sX
-                    a0 += sX[row * XP + 16 * bi + kk] * sS[p * 256 + kk * 16 + cc];
-                    a1 += sX[row * XP + 16 * bi + kk + 1] * sS[p * 256 + (kk + 1) * 16 + cc];
-                }
-                sX[row * XP + col] = -(a0 + a1);
+                for (int kc = 0; kc < 4; ++kc) // X_ii is lower triangular: its upper entries are exactly zero in sX
+                    res = __builtin_amdgcn_mfma_f64_16x16x4f64(sX[(16 * bi + li) * XP + 16 * bi + 4 * kc + lk], acc[kc], res, 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) sX[(16 * bi + 4 * v + lk) * XP + 16 * bj + li] = -res[v];
             }
             __syncthreads();
         }
     }
 
-    // ---- this workgroup's 16 rows of the slot: product, split, pack ------------------------------------
-    for (int idx = tid; idx < 16 * C; idx += 256) {
-        const int cl = idx / C, kc = idx % C, c = 16 * rgrp + cl;
-        double acc = 0.0;
+    IFL_FSTAMP(); // 2: off-diagonal blocks
+    // ---- this workgroup's 16 rows of the slot: product (fp64 matrix cores), split, pack -------------------------
+    // wave = 16 columns kc; lane (li, lk) ends up with rows cl = 4v + lk of column kc = 16 wave + li
+    if (wvf < C / 16) {
+        const int kc = 16 * wvf + li;
+        doublex4 acc = {0.0, 0.0, 0.0, 0.0};
         if (s == NT - 1) {
-            acc = transposed ? sX[kc * XP + c] : sX[c * XP + kc];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int c = 16 * rgrp + 4 * v + lk;
+                acc[v] = transposed ? sX[kc * XP + c] : sX[c * XP + kc];
+            }
         } else {
             // normal:     (W_t L^-1)[c][kc]     = sum_m W_t[c][m] Linv[m][kc]   (Linv[m][kc] = 0 for m < kc)
             // transposed: (W_t^T L^-T)[c][kc]   = sum_m W_t[m][c] Linv[kc][m]   (Linv[kc][m] = 0 for m > kc)
-            // the zeros are stored, so the sums run over all m: fixed trip count, unrolled, 4 chains
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-            const int xs_m = transposed ? 1 : XP, xs_0 = transposed ? kc * XP : kc;
+            // (sW holds the row c of either form as sW[m][c]; the zeros of L^-1 are stored: fixed trip count)
 #pragma unroll 4
-            for (int m = 0; m < C; m += 4) {
-                a0 += (double)sW[cl * C + m] * sX[xs_0 + m * xs_m];
-                a1 += (double)sW[cl * C + m + 1] * sX[xs_0 + (m + 1) * xs_m];
-                a2 += (double)sW[cl * C + m + 2] * sX[xs_0 + (m + 2) * xs_m];
-                a3 += (double)sW[cl * C + m + 3] * sX[xs_0 + (m + 3) * xs_m];
+            for (int mc = 0; mc < C / 4; ++mc) {
+                const int m = 4 * mc + lk;
+                const double bx = transposed ? sX[kc * XP + m] : sX[m * XP + kc];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)sW[m * 16 + li], bx, acc, 0, 0, 0);
             }
-            acc = -((a0 + a1) + (a2 + a3));
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[v] = -acc[v];
         }
-        const float v = (float)acc;
-        if (wf32) wf32[((size_t)s * C + kc) * C + c] = v; // fp32 copy [slot][kc][c] for the fp32 fallback scan
-        const _Float16 hi = (_Float16)v;
-        const _Float16 lo = (_Float16)((v - (float)hi) * LO_SCALE);
-        const int q = kc / 32, gk = (kc % 32) / 8, j = kc % 8;
-        const size_t base = ((((size_t)rgrp * NT + s) * NQ + q) * 2) * 64 * 8;
-        apack[base + (size_t)(cl + 16 * gk) * 8 + j] = hi;
-        apack[base + (size_t)64 * 8 + (size_t)(cl + 16 * gk) * 8 + j] = lo;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int cl = 4 * v + lk, c = 16 * rgrp + cl;
+            const float val = (float)acc[v];
+            if (wf32) wf32[((size_t)s * C + kc) * C + c] = val; // fp32 copy [slot][kc][c] for the fp32 fallback scan
+            const _Float16 hi = (_Float16)val;
+            const _Float16 lo = (_Float16)((val - (float)hi) * LO_SCALE);
+            const int q = kc / 32, gk = (kc % 32) / 8, j = kc % 8;
+            const size_t base = ((((size_t)rgrp * NT + s) * NQ + q) * 2) * 64 * 8;
+            apack[base + (size_t)(cl + 16 * gk) * 8 + j] = hi;
+            apack[base + (size_t)64 * 8 + (size_t)(cl + 16 * gk) * 8 + j] = lo;
+        }
     }
+    IFL_FSTAMP(); // 3: product + pack
+#ifdef IFL_STAMPS
+    if (g_stamps && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+        for (int k = 0; k < 4; ++k) g_stamps[72 + k] = ft[k];
+#endif
 }
 
 size_t scan_mfma_pack_bytes(const Geom &g) { return (size_t)g.KH * g.KW * g.C * g.C * 2 * sizeof(_Float16); }

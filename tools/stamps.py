@@ -7,7 +7,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "inverse-flow_amd")); sys.path.insert(0, ROOT)
 import torch
-buf = torch.zeros(8 * 8 + 8, dtype=torch.int64, device="cuda")
+buf = torch.zeros(8 * 8 + 16, dtype=torch.int64, device="cuda")
 os.environ["IFL_STAMPS"] = str(buf.data_ptr())
 import invflow_hip as H
 from bench import ref_init_weight, B, C, HH, WW
@@ -29,3 +29,4 @@ for k, name in enumerate(["no tile", "tile 0", "tile 1", "both tiles"]):
     c = int(full[68 + k]); tot = int(full[64 + k])
     if c:
         print("steps with", name, ":", c, "steps,", tot // c, "cycles each")
+print("fold (workgroup 0):", dict(zip(["loads", "diagonal blocks", "off-diagonal blocks", "product+pack"], full[72:76].tolist())))

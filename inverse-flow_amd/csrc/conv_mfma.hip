@@ -7,8 +7,8 @@
 //     (inf/utils/convbackward/conv2d_backward.cpp:32-53; a conv with the flipped kernel).
 // The first-correct direct kernel (conv_general.hip) stays for every other shape.
 //
-// One workgroup = one band of 8 output rows of one image; one wave = 16 output channels (one wave per SIMD).
-// The band's input (8 + KH-1 rows, W + KW-1 columns, zero halo) is staged once in LDS as split fp16
+// One workgroup = one band of 4 output rows of one image; one wave = 16 output channels (one wave per SIMD).
+// The band's input (4 + KH-1 rows, W + KW-1 columns, zero halo) is staged once in LDS as split fp16
 // (hi = fp16(v), lo' = fp16((v-hi) 2^11)) in the MFMA B-fragment layout [plane][pixel], plane = (k-step, hi/lo,
 // k-group of 8 channels), one 16-byte piece per pixel: the fragment of ANY tap is then a plain ds_read_b128 at
 // a pixel offset -- no im2col, no per-tap copies.  The weights live in AGPRs as split-fp16 A fragments (packed
@@ -18,6 +18,8 @@
 // A band whose input leaves the fp16 range (|v| >= 6e4) is redone in plain fp32 by the same workgroup.
 #include <type_traits>
 #include <utility>
+
+#include <stdlib.h>
 
 #include "ifl_common.h"
 #include "mfma_util.h"
@@ -33,7 +35,8 @@ template <int C, int KH, int KW, int WT> struct ConvCfg {
     static constexpr int NW = C / 16;  // waves = 16-channel output groups
     static constexpr int NQ = C / 32;  // 32-deep k-steps per tap
     static constexpr int NT = KH * KW;
-    static constexpr int RB = 8;                            // output rows per band
+    static constexpr int RB = 4;                            // output rows per band: 52 KB of LDS at C=64, W=32 -> three
+                                                            // workgroups per CU, one stages while another multiplies
     static constexpr int PR = RB + KH - 1, PC = WT + KW - 1; // staged rows / columns (halo included)
     static constexpr int PP = PR * PC;                      // staged pixels
     static constexpr int PB = PP * 16;                      // bytes of one plane
@@ -66,6 +69,10 @@ __global__ __launch_bounds__(256) void k_convpack(const float *__restrict__ w, _
     }
 }
 
+#ifdef IFL_STAMPS
+__device__ unsigned long long *g_cstamps = nullptr;
+#endif
+
 template <int C, int KH, int KW, int WT>
 __global__ __launch_bounds__(64 * (C / 16)) void k_conv_mfma(const float *__restrict__ in, const half8 *__restrict__ apack,
                                                               const float *__restrict__ w32,
@@ -83,6 +90,9 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_conv_mfma(const float *__rest
     const float *inb = in + (size_t)b * C * H * WT;
     float *outb = out + (size_t)b * C * H * WT;
 
+#ifdef IFL_STAMPS
+    const unsigned long long cs0 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- weights -> registers (pinned in the accumulator half of the register file, see scan_mfma.hip) ------------
     half8 A[NT][NQ][2];
 #pragma unroll
@@ -95,26 +105,45 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_conv_mfma(const float *__rest
                 asm volatile("" : "+a"(A[t][q][hl]));
             }
 
-    // ---- stage the band: item = (k-group of 8 channels, pixel), pixels fastest (coalesced along w) ---------------
+    // ---- stage the band.  Interior: item = (k-group of 8 channels, staged row, quad of 4 columns): eight 16-byte
+    //      loads (one per channel, lanes along w: fully coalesced), split, eight 16-byte LDS pieces per plane half.
+    //      Halo columns and rows outside the image are zero pieces. ------------------------------------------------
     float vmax = 0.f;
-    for (int it = tid; it < PP * (C / 8); it += Cfg::THREADS) {
-        const int kg = it / PP, p = it % PP;
-        const int rr = p / PC, cc = p % PC;
-        const int ih = h0 - pt + rr, iw = cc - pl;
-        const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < WT;
-        const float *src = inb + ((size_t)(8 * kg) * H + (ok ? ih : 0)) * WT + (ok ? iw : 0);
-        half8 hi, lo;
+    constexpr int QPR = WT / 4, PR = Cfg::PR;
+    for (int it = tid; it < (C / 8) * PR * QPR; it += Cfg::THREADS) {
+        const int qd = it % QPR, rr = (it / QPR) % PR, kg = it / (QPR * PR);
+        const int ih = h0 - pt + rr;
+        const bool ok = ih >= 0 && ih < H;
+        floatx4 v[8];
+        const float *src = inb + ((size_t)(8 * kg) * H + (ok ? ih : 0)) * WT + 4 * qd;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float v = ok ? src[(size_t)j * H * WT] : 0.f;
-            vmax = fmaxf(vmax, fabsf(v));
-            const _Float16 h16 = (_Float16)v;
-            hi[j] = h16;
-            lo[j] = (_Float16)((v - (float)h16) * LO_SCALE);
-        }
+        for (int j = 0; j < 8; ++j) v[j] = ok ? *(const floatx4 *)(src + (size_t)j * H * WT) : floatx4{0.f, 0.f, 0.f, 0.f};
         const int q = kg / 4, gk = kg % 4;
-        *(half8 *)(lds + ((q * 2 + 0) * 4 + gk) * PB + p * 16) = hi;
-        *(half8 *)(lds + ((q * 2 + 1) * 4 + gk) * PB + p * 16) = lo;
+        const int p0 = rr * PC + pl + 4 * qd; // staged pixel of the quad's first column
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            half8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = v[j][e];
+                vmax = fmaxf(vmax, fabsf(x));
+                const _Float16 h16 = (_Float16)x;
+                hi[j] = h16;
+                lo[j] = (_Float16)((x - (float)h16) * LO_SCALE);
+            }
+            *(half8 *)(lds + ((q * 2 + 0) * 4 + gk) * PB + (p0 + e) * 16) = hi;
+            *(half8 *)(lds + ((q * 2 + 1) * 4 + gk) * PB + (p0 + e) * 16) = lo;
+        }
+    }
+    {
+        const half8 zero8 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f,
+                             (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        constexpr int NHC = KW - 1; // halo columns: pl on the left, KW-1-pl on the right
+        for (int it = tid; it < Cfg::NPL * PR * NHC; it += Cfg::THREADS) {
+            const int hc = it % NHC, rr = (it / NHC) % PR, plane = it / (NHC * PR);
+            const int cc = hc < pl ? hc : WT + hc; // columns 0..pl-1 and pl+WT..PC-1
+            *(half8 *)(lds + plane * PB + (rr * PC + cc) * 16) = zero8;
+        }
     }
     // (also the barrier between staging and use)
     if (__syncthreads_or(vmax < 6.0e4f ? 0 : 1)) {
@@ -139,6 +168,9 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_conv_mfma(const float *__rest
         return;
     }
 
+#ifdef IFL_STAMPS
+    const unsigned long long cs1 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- multiply: tile pairs, taps double-buffered ---------------------------------------------------------
     const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
     const unsigned fa_lane = ldsbase + g * PB + n * 16; // this lane's piece of pixel 0 in plane (0, hi, g)
@@ -237,6 +269,13 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_conv_mfma(const float *__rest
 #pragma unroll
     for (int j = 0; j < NRD; ++j) request(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0, j);
     for (int p = 0; p < NP; p += 2) for_seq(std::make_integer_sequence<int, 2 * NT>{}, [&](auto s_c) { block_stage(s_c, p); });
+#ifdef IFL_STAMPS
+    if (g_cstamps && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
+        const unsigned long long cs2 = __builtin_amdgcn_s_memtime();
+        g_cstamps[wv * 2 + 0] = cs1 - cs0;
+        g_cstamps[wv * 2 + 1] = cs2 - cs1;
+    }
+#endif
 }
 
 bool conv_mfma_supported(int Ci, int Co, int H, int W, int OH, int OW, int KH, int KW, int pt, int pl)
@@ -261,6 +300,12 @@ static int launch_conv_one(const float *in, const void *apack, const float *w, c
                                     Cfg::LDSB));
         attr_done = true;
     }
+#ifdef IFL_STAMPS
+    if (const char *e = getenv("IFL_CSTAMPS")) {
+        unsigned long long *ptr = (unsigned long long *)strtoull(e, nullptr, 0);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cstamps), &ptr, sizeof(ptr));
+    }
+#endif
     const dim3 grid((H + Cfg::RB - 1) / Cfg::RB, B);
     hipLaunchKernelGGL((k_conv_mfma<C, KH, KW, WT>), grid, dim3(Cfg::THREADS), Cfg::LDSB, s, in, (const half8 *)apack, w,
                        bias, out, H, pt, pl);

@@ -1,0 +1,16 @@
+"""Staging / multiply cycle counts of the MFMA conv kernel (development aid; build with HIPCC_EXTRA=-DIFL_STAMPS)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "inverse-flow_amd")); sys.path.insert(0, ROOT)
+import torch
+buf = torch.zeros(8, dtype=torch.int64, device="cuda")
+os.environ["IFL_CSTAMPS"] = str(buf.data_ptr())
+import invflow_hip as H
+from bench import B, C, HH, WW
+x = torch.randn(B, C, HH, WW, device="cuda"); w = torch.randn(C, C, 3, 3, device="cuda") * 0.05
+for _ in range(3):
+    H.conv2d(x, w, None, (1, 1))
+torch.cuda.synchronize()
+t = buf.cpu().view(4, 2)
+for wv in range(4):
+    print("wave", wv, "stage", int(t[wv, 0]), "multiply", int(t[wv, 1]))

@@ -417,7 +417,8 @@ size_t ifl_conv2d_workspace_bytes(int B, int Ci, int Co, int H, int W, int KH, i
 {
     (void)B; (void)H; (void)W; (void)ph; (void)pw;
     if (Ci < 1 || Co < 1 || KH < 1 || KW < 1) return 0;
-    return align_up((size_t)Ci * Co * KH * KW * sizeof(float), 256) + 256 + conv_pack_bytes(Ci, Co, KH, KW);
+    return align_up((size_t)Ci * Co * KH * KW * sizeof(float), 256) + 256 + conv_pack_bytes(Ci, Co, KH, KW) +
+           (Ci == Co ? wgrad_mfma_workspace_bytes(B, Ci, H, KH, KW) + 512 : 0);
 }
 
 int ifl_conv2d_f32(const float *x, const float *w, const float *bias, float *z, int B, int Ci, int Co, int H, int W,
@@ -439,8 +440,6 @@ int ifl_conv2d_wgrad_f32(const float *gz, const float *x, float *dw, int B, int 
                          int KW, int ph, int pw, void *ws, size_t ws_bytes, ifl_stream_t stream)
 {
     clear_error();
-    (void)ws;
-    (void)ws_bytes;
     int rc = check_conv("ifl_conv2d_wgrad_f32", B, Ci, Co, H, W, KH, KW, ph, pw);
     if (rc) return rc;
     if (!gz || !x || !dw) IFL_FAIL(IFL_EINVAL, "ifl_conv2d_wgrad_f32: null tensor pointer");
@@ -448,6 +447,13 @@ int ifl_conv2d_wgrad_f32(const float *gz, const float *x, float *dw, int B, int 
     if (B == 0) {
         IFL_HIP(hipMemsetAsync(dw, 0, (size_t)Ci * Co * KH * KW * sizeof(float), (hipStream_t)stream));
         return IFL_OK;
+    }
+    if (Ci == Co && OH == H && OW == W && wgrad_mfma_supported(B, Ci, H, W, KH, KW, ph, pw, gz, x)) {
+        Carver cv(ws, ws_bytes);
+        void *wws = cv.take<unsigned char>(wgrad_mfma_workspace_bytes(B, Ci, H, KH, KW));
+        if (ws && cv.ok())
+            return launch_wgrad_mfma(gz, x, dw, wws, B, Ci, H, W, KH, KW, ph, pw, 1.0f, 0, 0, 0, nullptr, nullptr,
+                                     (hipStream_t)stream);
     }
     return launch_wgrad_direct(gz, x, dw, B, Ci, Co, H, W, OH, OW, KH, KW, ph, pw, 1.0f, 0, 0, 0, (hipStream_t)stream);
 }

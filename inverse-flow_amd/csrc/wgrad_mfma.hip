@@ -99,9 +99,9 @@ __device__ __forceinline__ void split8(const floatx4 &v0, const floatx4 &v1, flo
     }
 }
 
-// fragment shifted forward by J columns: element k <- element k+J; `head` = first dword of the next
-// 8-column block (already exchanged across the wave halves)
-template <int J> __device__ __forceinline__ half8 shift_frag(const half8 &f, unsigned head)
+// fragment shifted by J columns: element k <- element k+J.  `head` = first dword of the next 8-column block,
+// `tail` = last dword of the previous one (both already exchanged across the wave halves)
+template <int J> __device__ __forceinline__ half8 shift_frag(const half8 &f, unsigned head, unsigned tail)
 {
     const uintx4 d = __builtin_bit_cast(uintx4, f);
     uintx4 o;
@@ -112,11 +112,16 @@ template <int J> __device__ __forceinline__ half8 shift_frag(const half8 &f, uns
         o[1] = __builtin_amdgcn_alignbit(d[2], d[1], 16);
         o[2] = __builtin_amdgcn_alignbit(d[3], d[2], 16);
         o[3] = __builtin_amdgcn_alignbit(head, d[3], 16);
-    } else {
+    } else if (J == 2) {
         o[0] = d[1];
         o[1] = d[2];
         o[2] = d[3];
         o[3] = head;
+    } else { // J == -1
+        o[0] = __builtin_amdgcn_alignbit(d[0], tail, 16);
+        o[1] = __builtin_amdgcn_alignbit(d[1], d[0], 16);
+        o[2] = __builtin_amdgcn_alignbit(d[2], d[1], 16);
+        o[3] = __builtin_amdgcn_alignbit(d[3], d[2], 16);
     }
     return __builtin_bit_cast(half8, o);
 }
@@ -136,8 +141,11 @@ __device__ unsigned long long *g_wstamps = nullptr;
     } while (0)
 #endif
 
-// C channels, KHxKW taps (KW <= 3), NKS = W/16 k-steps per image row
-template <int C, int KH, int KW, int NKS>
+// C channels, KHxKW taps (KW <= 3), NKS = W/16 k-steps per image row.
+// CEN = 1: the centered ("same") padding of a 3x3 kernel (SelfNormConv, selfnorm.py:52-82): the canonical form with
+// the a operand one row late and one column to the right, G[i][j] = sum a[r - sg][s + j - 1] bb[r - sg i][s]; the
+// slice that ends the image runs one more step against a zero row of bb.
+template <int C, int KH, int KW, int NKS, int CEN>
 __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a, const float *__restrict__ bb,
                                                     float *__restrict__ partial, const unsigned *__restrict__ amax_a,
                                                     const unsigned *__restrict__ amax_b, int B, int H, int sg,
@@ -216,15 +224,24 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
         //   alternate (loop unrolled by two), so a load has two iterations to land and nothing ever waits on
         //   a load it has just issued.
         floatx4 ra[2][NKS][2], rb[2][NKS][2];
-        auto fetch = [&](auto set_c, int k) { // row number k of the slice (rows past it: re-read a valid row, never used)
+        // steps of this slice: one per row, plus (CEN) the step past the image's last row in walking direction
+        const int nsteps = nrows + ((CEN && (sg > 0 ? r_hi == H - 1 : r_lo == 0)) ? 1 : 0);
+        auto fetch = [&](auto set_c, int k) { // step k of the slice (steps past it: a valid row, never used)
             constexpr int SET = decltype(set_c)::value;
-            const int r = r_first + sg * (k < nrows ? k : nrows - 1);
+            const int rb_ = r_first + sg * k, ra_ = rb_ - sg * CEN; // a runs CEN rows late
+            const bool okb = rb_ >= 0 && rb_ < H, oka = ra_ >= 0 && ra_ < H;
+            const int rbc = okb ? rb_ : r_first, rac = oka ? ra_ : r_first;
+            const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                ra[SET][ks][0] = *(const floatx4 *)(ap + (size_t)r * W + 16 * ks);
-                ra[SET][ks][1] = *(const floatx4 *)(ap + (size_t)r * W + 16 * ks + 4);
-                rb[SET][ks][0] = *(const floatx4 *)(bpz + (size_t)r * W + 16 * ks);
-                rb[SET][ks][1] = *(const floatx4 *)(bpz + (size_t)r * W + 16 * ks + 4);
+                ra[SET][ks][0] = *(const floatx4 *)(ap + (size_t)rac * W + 16 * ks);
+                ra[SET][ks][1] = *(const floatx4 *)(ap + (size_t)rac * W + 16 * ks + 4);
+                rb[SET][ks][0] = *(const floatx4 *)(bpz + (size_t)rbc * W + 16 * ks);
+                rb[SET][ks][1] = *(const floatx4 *)(bpz + (size_t)rbc * W + 16 * ks + 4);
+                if (CEN) { // rows outside the image are zero rows (without CEN they are never used)
+                    if (!oka) ra[SET][ks][0] = ra[SET][ks][1] = zero;
+                    if (!okb) rb[SET][ks][0] = rb[SET][ks][1] = zero;
+                }
             }
         };
         using S0 = std::integral_constant<int, 0>;
@@ -248,7 +265,7 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
             // heads of the next 8-column block, exchanged across the two wave halves:
             // a lane with hh=0 needs the hh=1 lane's block of the same k-step, a lane with hh=1 the
             // hh=0 lane's block of the next k-step (zero past the row end)
-            unsigned head[NKS][2];
+            unsigned head[NKS][2], tail[NKS][2];
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
@@ -260,6 +277,16 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
                     // the low half's values in both halves, the second the high half's
                     const auto sw = __builtin_amdgcn_permlane32_swap(send, send, false, false);
                     head[ks][hl] = hh ? sw[0] : sw[1];
+                    tail[ks][hl] = 0u;
+                    if (CEN) {
+                        // tails of the previous 8-column block: a lane with hh=1 needs the hh=0 lane's block of the
+                        // same k-step, a lane with hh=0 the hh=1 lane's block of the previous k-step (zero at the row start)
+                        const unsigned ownt = __builtin_bit_cast(uintx4, Au[ks][hl])[3];
+                        const unsigned prvt = ks > 0 ? __builtin_bit_cast(uintx4, Au[ks > 0 ? ks - 1 : 0][hl])[3] : 0u;
+                        const unsigned sendt = hh ? prvt : ownt;
+                        const auto swt = __builtin_amdgcn_permlane32_swap(sendt, sendt, false, false);
+                        tail[ks][hl] = hh ? swt[0] : swt[1];
+                    }
                 }
             // note: the hh=1 lane of the LAST k-step receives `nxt` of its partner = 0 (row end) as
             // intended; the hh=0 lane receives the partner's own block.
@@ -268,9 +295,9 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
             for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
                 for (int hl = 0; hl < 2; ++hl) {
-                    As[0][ks][hl] = shift_frag<0>(Au[ks][hl], head[ks][hl]);
-                    if constexpr (KW > 1) As[1][ks][hl] = shift_frag<1>(Au[ks][hl], head[ks][hl]);
-                    if constexpr (KW > 2) As[2][ks][hl] = shift_frag<2>(Au[ks][hl], head[ks][hl]);
+                    As[0][ks][hl] = shift_frag<0 - CEN>(Au[ks][hl], head[ks][hl], tail[ks][hl]);
+                    if constexpr (KW > 1) As[1][ks][hl] = shift_frag<1 - CEN>(Au[ks][hl], head[ks][hl], tail[ks][hl]);
+                    if constexpr (KW > 2) As[2][ks][hl] = shift_frag<2 - CEN>(Au[ks][hl], head[ks][hl], tail[ks][hl]);
                 }
             __builtin_amdgcn_sched_barrier(0);
             IFL_WSTAMP(1); // shifts
@@ -320,11 +347,11 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
             IFL_WSTAMP(2); // loads + roll
         };
         int step = 0;
-        for (; step + 1 < nrows; step += 2) {
+        for (; step + 1 < nsteps; step += 2) {
             row_step(S1{}, step);
             row_step(S0{}, step + 1);
         }
-        if (step < nrows) row_step(S1{}, step);
+        if (step < nsteps) row_step(S1{}, step);
     }
     IFL_WSTAMP(4);
 
@@ -442,7 +469,9 @@ bool wgrad_mfma_supported(int B, int C, int H, int W, int KH, int KW, int pt, in
     if (!(W == 16 || W == 32)) return false;
     if (KH < 1 || KH > 3 || KW < 1 || KW > 3 || KH != KW) return false;
     if (!(KH == 3 || KH == 2)) return false;
-    if (!((pt == 0 || pt == KH - 1) && (pl == 0 || pl == KW - 1))) return false;
+    const bool corner = (pt == 0 || pt == KH - 1) && (pl == 0 || pl == KW - 1);
+    const bool centered = KH == 3 && KW == 3 && pt == 1 && pl == 1; // SelfNormConv's "same" padding
+    if (!corner && !centered) return false;
     if (KH == 1 || KW == 1) return false;
     if (B < 1 || H < 1) return false;
     if (((uintptr_t)gz | (uintptr_t)x) & 15) return false;
@@ -457,7 +486,7 @@ size_t wgrad_mfma_workspace_bytes(int B, int C, int H, int KH, int KW)
     return 256 + (size_t)nsplit * KH * KW * C * C * sizeof(float);
 }
 
-template <int C, int KH, int KW, int NKS>
+template <int C, int KH, int KW, int NKS, int CEN>
 static int launch_wg(const float *a, const float *bb, float *partial, const unsigned *amax_a, const unsigned *amax_b,
                      int B, int H, int sg, hipStream_t s)
 {
@@ -467,7 +496,7 @@ static int launch_wg(const float *a, const float *bb, float *partial, const unsi
     const size_t lds = (size_t)2 * KH * KW * 4 * 64 * sizeof(floatx4);
     static bool attr_done = false; // idempotent attribute, benign race
     if (!attr_done) {
-        IFL_HIP(hipFuncSetAttribute((const void *)k_wgrad_mfma<C, KH, KW, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        IFL_HIP(hipFuncSetAttribute((const void *)k_wgrad_mfma<C, KH, KW, NKS, CEN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
         attr_done = true;
     }
@@ -477,7 +506,7 @@ static int launch_wg(const float *a, const float *bb, float *partial, const unsi
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wstamps), &ptr, sizeof(ptr));
     }
 #endif
-    hipLaunchKernelGGL((k_wgrad_mfma<C, KH, KW, NKS>), dim3(nsplit * NB * NB), dim3(256), lds, s, a, bb, partial, amax_a,
+    hipLaunchKernelGGL((k_wgrad_mfma<C, KH, KW, NKS, CEN>), dim3(nsplit * NB * NB), dim3(256), lds, s, a, bb, partial, amax_a,
                        amax_b, B, H, sg, ntask);
     IFL_HIP(hipGetLastError());
     return IFL_OK;
@@ -501,14 +530,17 @@ int launch_wgrad_mfma(const float *gz, const float *x, float *dw, void *ws, int 
         amax_gz = absmax;
         amax_x = absmax + 1;
     }
-    const int top = pt != 0, left = pl != 0;
-    // canonical form (see header): L orders shift gz, R orders shift x and transpose the result
-    const int swapped = !left;
+    const bool centered = KH == 3 && KW == 3 && pt == 1 && pl == 1;
+    // canonical form (see header): L orders shift gz, R orders shift x and transpose the result; the centered
+    // padding is the transposed form walked downwards with x one row late and one column right (kernel's CEN)
+    const int top = centered ? 0 : pt != 0, left = centered ? 0 : pl != 0;
+    const int swapped = centered ? 1 : !left;
     const float *a = swapped ? x : gz, *bb = swapped ? gz : x;
-    const int sg = (top != swapped) ? +1 : -1; // TL:+1  BL:-1  TR:-1  BR:+1
+    const int sg = centered ? +1 : ((top != swapped) ? +1 : -1); // TL:+1  BL:-1  TR:-1  BR:+1
     int rc = IFL_EUNSUPPORTED;
-#define IFL_CASE(CC, KK, NN) \
-    if (C == CC && KH == KK && W == 16 * NN) rc = launch_wg<CC, KK, KK, NN>(a, bb, partial, swapped ? amax_x : amax_gz, swapped ? amax_gz : amax_x, B, H, sg, s);
+#define IFL_CASE(CC, KK, NN)                                                                                               \
+    if (C == CC && KH == KK && W == 16 * NN && !centered)                                                                   \
+        rc = launch_wg<CC, KK, KK, NN, 0>(a, bb, partial, swapped ? amax_x : amax_gz, swapped ? amax_gz : amax_x, B, H, sg, s);
     IFL_CASE(64, 3, 2)
     IFL_CASE(64, 3, 1)
     IFL_CASE(32, 3, 2)
@@ -517,6 +549,14 @@ int launch_wgrad_mfma(const float *gz, const float *x, float *dw, void *ws, int 
     IFL_CASE(64, 2, 1)
     IFL_CASE(32, 2, 2)
     IFL_CASE(32, 2, 1)
+#undef IFL_CASE
+#define IFL_CASE(CC, KK, NN)                                                                                               \
+    if (C == CC && KH == KK && W == 16 * NN && centered)                                                                    \
+        rc = launch_wg<CC, KK, KK, NN, 1>(a, bb, partial, swapped ? amax_x : amax_gz, swapped ? amax_gz : amax_x, B, H, sg, s);
+    IFL_CASE(64, 3, 2)
+    IFL_CASE(64, 3, 1)
+    IFL_CASE(32, 3, 2)
+    IFL_CASE(32, 3, 1)
 #undef IFL_CASE
     if (rc == IFL_EUNSUPPORTED) IFL_FAIL(rc, "launch_wgrad_mfma: no instantiation for C=%d K=%d W=%d", C, KH, W);
     if (rc) return rc;

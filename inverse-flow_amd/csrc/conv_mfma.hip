@@ -7,7 +7,8 @@
 //     (inf/utils/convbackward/conv2d_backward.cpp:32-53; a conv with the flipped kernel).
 // The first-correct direct kernel (conv_general.hip) stays for every other shape.
 //
-// One workgroup = one band of 4 output rows of one image; one wave = 16 output channels (one wave per SIMD).
+// One workgroup = four bands of 4 output rows of one image, one after the other (the loads of the next band are in
+// flight while the current one multiplies); one wave = 16 output channels (one wave per SIMD).
 // The band's input (4 + KH-1 rows, W + KW-1 columns, zero halo) is staged once in LDS as split fp16
 // (hi = fp16(v), lo' = fp16((v-hi) 2^11)) in the MFMA B-fragment layout [plane][pixel], plane = (k-step, hi/lo,
 // k-group of 8 channels), one 16-byte piece per pixel: the fragment of ANY tap is then a plain ds_read_b128 at
@@ -45,6 +46,7 @@ template <int C, int KH, int KW, int WT> struct ConvCfg {
     static constexpr int THREADS = 64 * NW;
     static constexpr int TPR = WT / 16;      // 16-pixel tiles per row
     static constexpr int NP = RB * TPR / 2;  // tile pairs per band
+    static constexpr int BPW = 4;            // bands per workgroup: the next band's loads fly while this one multiplies
     static_assert(WT % 16 == 0 && (RB * TPR) % 2 == 0 && NP % 2 == 0, "tiles come in pairs, pairs in pairs");
     static_assert(LDSB <= 160 * 1024, "band staging must fit the CU's LDS");
     static_assert(4 * PB + (KH * PC + KW) * 16 < 65536, "fragment offsets must fit the ds offset field");
@@ -86,7 +88,9 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_conv_mfma(const float *__rest
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, g = lane >> 4;
-    const int b = blockIdx.y, h0 = blockIdx.x * RB;
+    const int b = blockIdx.y;
+    const int band0 = blockIdx.x * Cfg::BPW, nbands = (H + RB - 1) / RB;
+    const int band1 = band0 + Cfg::BPW < nbands ? band0 + Cfg::BPW : nbands; // this workgroup's bands [band0, band1)
     const float *inb = in + (size_t)b * C * H * WT;
     float *outb = out + (size_t)b * C * H * WT;
 
@@ -105,36 +109,54 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_conv_mfma(const float *__rest
                 asm volatile("" : "+a"(A[t][q][hl]));
             }
 
-    // ---- stage the band.  Interior: item = (k-group of 8 channels, staged row, quad of 4 columns): eight 16-byte
-    //      loads (one per channel, lanes along w: fully coalesced), split, eight 16-byte LDS pieces per plane half.
-    //      Halo columns and rows outside the image are zero pieces. ------------------------------------------------
-    float vmax = 0.f;
+    // ---- staging.  Interior: item = (k-group of 8 channels, staged row, quad of 4 columns): eight 16-byte loads
+    //      (one per channel, lanes along w: fully coalesced) into registers -- issued for the NEXT band before the
+    //      current one is multiplied, so that the memory time of a band hides behind the MFMAs of its predecessor --
+    //      then split and written as eight 16-byte LDS pieces per plane half.  Rows outside the image arrive as zeros,
+    //      the halo columns are zero pieces written once. ----------------------------------------------------------
     constexpr int QPR = WT / 4, PR = Cfg::PR;
-    for (int it = tid; it < (C / 8) * PR * QPR; it += Cfg::THREADS) {
-        const int qd = it % QPR, rr = (it / QPR) % PR, kg = it / (QPR * PR);
-        const int ih = h0 - pt + rr;
-        const bool ok = ih >= 0 && ih < H;
-        floatx4 v[8];
-        const float *src = inb + ((size_t)(8 * kg) * H + (ok ? ih : 0)) * WT + 4 * qd;
+    constexpr int NITEM = (C / 8) * PR * QPR, NIT = (NITEM + Cfg::THREADS - 1) / Cfg::THREADS;
+    floatx4 raw[NIT][8];
+    auto fetch = [&](int band) {
+        const int h0 = band * RB;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = ok ? *(const floatx4 *)(src + (size_t)j * H * WT) : floatx4{0.f, 0.f, 0.f, 0.f};
-        const int q = kg / 4, gk = kg % 4;
-        const int p0 = rr * PC + pl + 4 * qd; // staged pixel of the quad's first column
+        for (int u = 0; u < NIT; ++u) {
+            const int it = tid + u * Cfg::THREADS;
+            const int qd = it % QPR, rr = (it / QPR) % PR, kg = (it / (QPR * PR)) % (C / 8);
+            const int ih = h0 - pt + rr;
+            const bool ok = it < NITEM && ih >= 0 && ih < H;
+            const float *src = inb + ((size_t)(8 * kg) * H + (ok ? ih : 0)) * WT + 4 * qd;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            half8 hi, lo;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float x = v[j][e];
-                vmax = fmaxf(vmax, fabsf(x));
-                const _Float16 h16 = (_Float16)x;
-                hi[j] = h16;
-                lo[j] = (_Float16)((x - (float)h16) * LO_SCALE);
-            }
-            *(half8 *)(lds + ((q * 2 + 0) * 4 + gk) * PB + (p0 + e) * 16) = hi;
-            *(half8 *)(lds + ((q * 2 + 1) * 4 + gk) * PB + (p0 + e) * 16) = lo;
+            for (int j = 0; j < 8; ++j) raw[u][j] = ok ? *(const floatx4 *)(src + (size_t)j * H * WT) : floatx4{0.f, 0.f, 0.f, 0.f};
         }
-    }
+    };
+    auto convert = [&]() -> float {
+        float vmax = 0.f;
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int it = tid + u * Cfg::THREADS;
+            if (it < NITEM) {
+                const int qd = it % QPR, rr = (it / QPR) % PR, kg = it / (QPR * PR);
+                const int q = kg / 4, gk = kg % 4;
+                const int p0 = rr * PC + pl + 4 * qd; // staged pixel of the quad's first column
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    half8 hi, lo;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float x = raw[u][j][e];
+                        vmax = fmaxf(vmax, fabsf(x));
+                        const _Float16 h16 = (_Float16)x;
+                        hi[j] = h16;
+                        lo[j] = (_Float16)((x - (float)h16) * LO_SCALE);
+                    }
+                    *(half8 *)(lds + ((q * 2 + 0) * 4 + gk) * PB + (p0 + e) * 16) = hi;
+                    *(half8 *)(lds + ((q * 2 + 1) * 4 + gk) * PB + (p0 + e) * 16) = lo;
+                }
+            }
+        }
+        return vmax;
+    };
     {
         const half8 zero8 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f,
                              (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
@@ -145,9 +167,8 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_conv_mfma(const float *__rest
             *(half8 *)(lds + plane * PB + (rr * PC + cc) * 16) = zero8;
         }
     }
-    // (also the barrier between staging and use)
-    if (__syncthreads_or(vmax < 6.0e4f ? 0 : 1)) {
-        // the band leaves the fp16 range (or holds a NaN/Inf): plain fp32, straight from memory.  Rare and slow.
+    // a band that leaves the fp16 range (or holds a NaN/Inf): plain fp32, straight from memory.  Rare and slow.
+    auto band_fp32 = [&](int h0) {
         for (int o = tid; o < C * RB * WT; o += Cfg::THREADS) {
             const int ow = o % WT, r = (o / WT) % RB, co = o / (WT * RB);
             const int oh = h0 + r;
@@ -165,13 +186,10 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_conv_mfma(const float *__rest
                 }
             outb[((size_t)co * H + oh) * WT + ow] = acc;
         }
-        return;
-    }
+    };
 
-#ifdef IFL_STAMPS
-    const unsigned long long cs1 = __builtin_amdgcn_s_memtime();
-#endif
     // ---- multiply: tile pairs, taps double-buffered ---------------------------------------------------------
+    int h0 = 0; // first output row of the band being multiplied
     const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
     const unsigned fa_lane = ldsbase + g * PB + n * 16; // this lane's piece of pixel 0 in plane (0, hi, g)
     const int c0 = 16 * wv + 4 * g;                    // C/D layout: lane (n, g) holds channels c0..c0+3 of pixel n
@@ -266,15 +284,25 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_conv_mfma(const float *__rest
         if (TAP == NT - 1) epilogue(pc);
     };
 
+    fetch(band0);
+    for (int band = band0; band < band1; ++band) {
+        h0 = band * RB;
+        const float vmax = convert(); // (waits for the band's loads)
+        // (also the barrier between staging and use)
+        const int ovf = __syncthreads_or(vmax < 6.0e4f ? 0 : 1);
+        if (band + 1 < band1) fetch(band + 1); // in flight while this band multiplies
+        if (ovf) {
+            band_fp32(h0);
+        } else {
 #pragma unroll
-    for (int j = 0; j < NRD; ++j) request(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0, j);
-    for (int p = 0; p < NP; p += 2) for_seq(std::make_integer_sequence<int, 2 * NT>{}, [&](auto s_c) { block_stage(s_c, p); });
-#ifdef IFL_STAMPS
-    if (g_cstamps && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
-        const unsigned long long cs2 = __builtin_amdgcn_s_memtime();
-        g_cstamps[wv * 2 + 0] = cs1 - cs0;
-        g_cstamps[wv * 2 + 1] = cs2 - cs1;
+            for (int j = 0; j < NRD; ++j) request(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0, j);
+            for (int p = 0; p < NP; p += 2)
+                for_seq(std::make_integer_sequence<int, 2 * NT>{}, [&](auto s_c) { block_stage(s_c, p); });
+        }
+        __syncthreads(); // every wave is done with the staged band before the next one overwrites it
     }
+#ifdef IFL_STAMPS
+    if (g_cstamps && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) g_cstamps[wv] = __builtin_amdgcn_s_memtime() - cs0;
 #endif
 }
 
@@ -306,7 +334,8 @@ static int launch_conv_one(const float *in, const void *apack, const float *w, c
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cstamps), &ptr, sizeof(ptr));
     }
 #endif
-    const dim3 grid((H + Cfg::RB - 1) / Cfg::RB, B);
+    const int nbands = (H + Cfg::RB - 1) / Cfg::RB;
+    const dim3 grid((nbands + Cfg::BPW - 1) / Cfg::BPW, B);
     hipLaunchKernelGGL((k_conv_mfma<C, KH, KW, WT>), grid, dim3(Cfg::THREADS), Cfg::LDSB, s, in, (const half8 *)apack, w,
                        bias, out, H, pt, pl);
     IFL_HIP(hipGetLastError());

@@ -1,4 +1,4 @@
-"""Staging / multiply cycle counts of the MFMA conv kernel (development aid; build with HIPCC_EXTRA=-DIFL_STAMPS)."""
+"""Cycle count of one workgroup of the MFMA conv kernel (development aid; build with HIPCC_EXTRA=-DIFL_STAMPS)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "inverse-flow_amd")); sys.path.insert(0, ROOT)
@@ -11,6 +11,6 @@ x = torch.randn(B, C, HH, WW, device="cuda"); w = torch.randn(C, C, 3, 3, device
 for _ in range(3):
     H.conv2d(x, w, None, (1, 1))
 torch.cuda.synchronize()
-t = buf.cpu().view(4, 2)
+t = buf.cpu()
 for wv in range(4):
-    print("wave", wv, "stage", int(t[wv, 0]), "multiply", int(t[wv, 1]))
+    print("wave", wv, "cycles for the workgroup's bands", int(t[wv]))

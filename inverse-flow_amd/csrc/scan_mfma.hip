@@ -180,6 +180,7 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
     float rmax = 0.f;       // max |r| this lane put into the ring: beyond the fp16 range the image is redone in fp32
     float zmax = 0.f;       // max |z| this lane stored (handed to the weight-gradient kernel as its prescale)
     int qprev = 0;          // in-row staging offset (parity, position in the quad) of the previous step's column
+    float xscale = 1.f, zscale = 1.f; // scaled retries of an image whose r left the fp16 range
     // kernel arguments used in the loop, held in scalar registers (a reload would wait on the LDS counter)
     int Hs = H, Ws = W;
     asm volatile("" : "+s"(Hs), "+s"(Ws));
@@ -239,8 +240,9 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
         ro_loff = ro_lds + __mul24(hr, Cfg::XROWB) + ((wq >> 2) & 1) * (C * 16);
         ro_okm = ok ? -1 : 0;
     };
-    auto step = [&](auto mask_c, const int d) {
+    auto step = [&](auto mask_c, auto scaled_c, const int d) {
         constexpr int MASK = decltype(mask_c)::value;
+        constexpr bool SCALED = decltype(scaled_c)::value; // a retry with x scaled down (see the sweep below)
         constexpr int NA = (MASK & 1) + ((MASK >> 1) & 1);
         constexpr int NDH = KH < 2 ? KH : 2;
         constexpr int PER = NA * NQ * 2; // reads per fragment set
@@ -369,7 +371,8 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
                 if (MASK & (1 << T)) {
                     unsigned char *zp = zq + xadr[T] + qprev;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) *(float *)(zp + r * 16) = zh[T][r] + zm[T][r] * LO_INV;
+                    for (int r = 0; r < 4; ++r)
+                        *(float *)(zp + r * 16) = SCALED ? (zh[T][r] + zm[T][r] * LO_INV) * zscale : zh[T][r] + zm[T][r] * LO_INV;
                 }
         };
         // ---- chunk: store role ----------------------------------------------------------------------------
@@ -413,7 +416,8 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
             const bool valid = hval[T] && (unsigned)w < (unsigned)Ws;
             float rv[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) rv[r] = xq[T][r >> 1][r & 1] + ahi[T][0][r] + amid[T][0][r] * LO_INV;
+            for (int r = 0; r < 4; ++r)
+                rv[r] = (SCALED ? xq[T][r >> 1][r & 1] * xscale : xq[T][r >> 1][r & 1]) + ahi[T][0][r] + amid[T][0][r] * LO_INV;
             half4 hi, lo;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -614,24 +618,26 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
     // the step after its last one (the z product of the last diagonal): the sets of active tiles come in the
     // order {}, {0}, {0,1}, {1}, {} -- one loop per set, so that no control flow merges inside a step.  The last
     // step stores the quads staged by the one before.
-    {
+    auto sweep = [&](auto scaled_c) {
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
         const int last0 = (15 + W - 1 < ND - 1 ? 15 + W - 1 : ND - 1) + 1; // last step of tile 0
         int d = -3;
         ro_stage(d);
-        step(I0{}, d++);
+        step(I0{}, scaled_c, d++);
         if constexpr (NTILE == 2) {
             using I2 = std::integral_constant<int, 2>;
             using I3 = std::integral_constant<int, 3>;
-            for (; d < 14; ++d) step(I1{}, d);
-            for (; d <= last0; ++d) step(I3{}, d);
-            for (; d <= ND; ++d) step(I2{}, d);
+            for (; d < 14; ++d) step(I1{}, scaled_c, d);
+            for (; d <= last0; ++d) step(I3{}, scaled_c, d);
+            for (; d <= ND; ++d) step(I2{}, scaled_c, d);
         } else {
-            for (; d <= last0; ++d) step(I1{}, d);
+            for (; d <= last0; ++d) step(I1{}, scaled_c, d);
         }
-        for (; d <= ND + 2; ++d) step(I0{}, d);
-    }
+        for (; d <= ND + 2; ++d) step(I0{}, scaled_c, d);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every DMA and store of the sweep has retired
+    };
+    sweep(std::false_type{});
 
 #ifdef IFL_STAMPS
     if (g_stamps && b == 0 && lane == 0)
@@ -642,13 +648,47 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
             g_stamps[68 + k] = st_cnt[k];
         }
 #endif
-    // Split fp16 cannot hold |r| >= 65504 (a badly conditioned operator grows r along the sweep): such an
-    // image is redone here, by the same workgroup, in exact fp32 from the fp32 copy of the same folded
-    // weights (general scan body, right-fold form).  Rare, slow, but never a silent Inf/NaN where the exact
-    // solver is finite.  flags[] records it for the caller (diagnostics only).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no LDS-DMA may still be landing in the LDS reused below
-    const int redo = __syncthreads_or(rmax < 6.0e4f ? 0 : 1);
-    if (tid == 0) flags[b] = redo ? 1 : 0; // every workgroup owns its word: no clearing pass needed
+    // Split fp16 cannot hold |r| >= 65504, and a badly conditioned operator grows r along the sweep.  Such an image
+    // is swept once more by the same workgroup with x scaled down by 2^-12 and z scaled back up: the recurrence is
+    // linear, inputs of order one still split into a normal fp16 hi and a lo that keeps the rest (22 bits), and r may
+    // now reach 2.4e8.  A second, deeper rescale would push the early (small) diagonals into fp16 denormals, whose
+    // rounding the growth then amplifies (measured 1e-4 at max|z| = 1e11): beyond the first rescale, or when the input
+    // is not finite, the exact fp32 body takes over (general scan body, right-fold form, fp32 copy of the same folded
+    // weights): slow, but never a silent Inf/NaN where the exact solver is finite.  flags[] records what happened
+    // (diagnostics only: 0, 1 = rescaled, +4 = fp32).
+    int redo = __syncthreads_or(rmax < 6.0e4f ? 0 : 1);
+    int attempts = 0;
+    while (redo && attempts < 1) {
+        ++attempts;
+        xscale *= 1.0f / 4096.0f;
+        zscale *= 4096.0f;
+        {
+            const floatx4 zz = {0.f, 0.f, 0.f, 0.f};
+            for (int i = tid * 16; i < Cfg::RINGB; i += Cfg::THREADS * 16) *(floatx4 *)(lds + i) = zz;
+        }
+#pragma unroll
+        for (int T = 0; T < NTILE; ++T) {
+#pragma unroll
+            for (int k = 0; k < Cfg::NACC; ++k) {
+                ahi[T][k] = floatx4{0.f, 0.f, 0.f, 0.f};
+                amid[T][k] = floatx4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    F2h[T][q][j] = (_Float16)0.f;
+                    F2l[T][q][j] = (_Float16)0.f;
+                }
+        }
+        rmax = 0.f;
+        zmax = 0.f;
+        qprev = 0;
+        __syncthreads();
+        sweep(std::true_type{});
+        redo = __syncthreads_or(rmax < 6.0e4f ? 0 : 1);
+    }
+    if (tid == 0) flags[b] = attempts + (redo ? 4 : 0); // every workgroup owns its word: no clearing pass needed
     if (redo) {
         scan_general_body<Cfg::THREADS>(xin, wf32, zout, geom, rh, rw, 1, (float *)lds, b, tid);
         if (amax) { // the quads stored above are void: take the maximum of what the redo wrote

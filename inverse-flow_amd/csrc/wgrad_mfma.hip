@@ -86,6 +86,16 @@ __device__ __forceinline__ float pow2_scale(unsigned maxbits)
     return __uint_as_float((unsigned)se << 23);
 }
 
+// Split fp16 keeps 22 bits below each tensor's maximum.  Tensors that have grown by 2^24 or more along the sweep (an
+// ill-conditioned layer: max|z| or max|dx| >= 1.7e7 for inputs of order one) peak in opposite corners, so that the
+// products that make up dW pair the large entries of one with the small ones of the other: there the contraction is
+// done in plain fp32 instead (by the reduce kernel).  Also taken when a maximum is not finite.
+__device__ __forceinline__ bool wgrad_wide_range(unsigned a_bits, unsigned b_bits)
+{
+    const unsigned m = a_bits > b_bits ? a_bits : b_bits;
+    return m >= 0x4B800000u; // 2^24 as a float bit pattern (non-negative floats order like unsigned; Inf/NaN above)
+}
+
 __device__ __forceinline__ void split8(const floatx4 &v0, const floatx4 &v1, float s, half8 &hi, half8 &lo)
 {
 #pragma unroll
@@ -162,6 +172,7 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
     const int bp = blk / NB, bq = blk % NB; // block row (a channels) / column (bb channels)
 
     // max|a|, max|bb| as float bit patterns (upper bounds are fine: they only pick a power-of-two scale)
+    if (wgrad_wide_range(*amax_a, *amax_b)) return; // (uniform) the reduce kernel computes dW in fp32 instead
     const float sa = pow2_scale(*amax_a);
     const float sb = pow2_scale(*amax_b);
 
@@ -416,10 +427,44 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
                                                       const unsigned *__restrict__ amax_a,
                                                       const unsigned *__restrict__ amax_b, int nsplit, int C, int KH,
                                                       int KW, int swapped, int top, int left, float scale,
-                                                      int mask_mode, int mkh, int mkw)
+                                                      int mask_mode, int mkh, int mkw, const float *__restrict__ gz,
+                                                      const float *__restrict__ x, int B, int H, int W, int pt, int pl)
 {
     const int NT = KH * KW, NB = C / 32;
     const size_t total4 = (size_t)NB * NB * NT * 4 * 64; // float4 elements of one partial
+    if (wgrad_wide_range(*amax_a, *amax_b)) {
+        // plain fp32 contraction (see wgrad_wide_range): a wave owns row e = its index of each of the block's 64
+        // float4 elements in turn; its lanes stride over the pixels (coalesced along w), fixed-order butterfly
+        const int l = threadIdx.x & 63, e = threadIdx.x >> 6;
+        const size_t npix = (size_t)B * H * W;
+        for (int o = 0; o < 64; ++o) {
+            const size_t ido = (size_t)blockIdx.x * 64 + o;
+            if (ido >= total4) break;
+            const int lane = (int)(ido % 64), v = (int)((ido / 64) % 4), t = (int)((ido / 256) % NT), blk = (int)(ido / (256 * (size_t)NT));
+            const int bp = blk / NB, bq = blk % NB, m = lane & 31, hh = lane >> 5;
+            const int i = t / KW, j = t % KW;
+            const int kh = top ? KH - 1 - i : i, kw = left ? KW - 1 - j : j;
+            const int q = 32 * bq + m, p = 32 * bp + e + 8 * v + 4 * hh;
+            const int co = swapped ? q : p, ci = swapped ? p : q;
+            float acc = 0.f;
+            for (size_t pix = l; pix < npix; pix += 64) {
+                const int ow = (int)(pix % W), oh = (int)((pix / W) % H), b = (int)(pix / ((size_t)W * H));
+                const int ih = oh - pt + kh, iw = ow - pl + kw;
+                if (ih >= 0 && ih < H && iw >= 0 && iw < W)
+                    acc = fmaf(gz[(((size_t)b * C + co) * H + oh) * W + ow], x[(((size_t)b * C + ci) * H + ih) * W + iw], acc);
+            }
+            for (int sft = 32; sft > 0; sft >>= 1) acc += __shfl_xor(acc, sft, 64);
+            if (l == 0) {
+                float val = acc * scale;
+                if (mask_mode && kh == mkh && kw == mkw) {
+                    if (mask_mode == 1 && ci >= co) val = 0.f;
+                    if (mask_mode == 2 && ci > co) val = 0.f;
+                }
+                dw[(((size_t)co * C + ci) * KH + kh) * KW + kw] = val;
+            }
+        }
+        return;
+    }
     const float inv = scale / (pow2_scale(*amax_a) * pow2_scale(*amax_b));
     const int sub = threadIdx.x >> 6;                                // wave index = partial residue class
     const size_t idx = (size_t)blockIdx.x * 64 + (threadIdx.x & 63); // float4 element
@@ -564,7 +609,7 @@ int launch_wgrad_mfma(const float *gz, const float *x, float *dw, void *ws, int 
     const size_t total4 = (size_t)KH * KW * C * C / 4;
     size_t blocks = (total4 + 63) / 64;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)blocks), dim3(256), 0, s, partial, dw, amax_gz, amax_x, nsplit, C, KH, KW,
-                       swapped, top, left, scale, mask_mode, mkh, mkw);
+                       swapped, top, left, scale, mask_mode, mkh, mkw, gz, x, B, H, W, pt, pl);
     IFL_HIP(hipGetLastError());
     return IFL_OK;
 }

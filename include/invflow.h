@@ -117,6 +117,22 @@ int ifl_backward_f32(const float *g, const float *z, const float *x, const float
                      int order, unsigned flags, void *ws, size_t ws_bytes, void *carry, ifl_stream_t stream);
 
 /*
+ * The inverse-flow block: four layers of orders TL -> TR -> BL -> BR (Inv_FlowUnit, inf/layers/inv_flow.py:13-53).
+ *   z[0] = A_TL^-1 x, z[1] = A_TR^-1 z[0], z[2] = A_BL^-1 z[1], z[3] = A_BR^-1 z[2]   (all kept: the backward needs them)
+ * ONE fold launch serves the four layers (and, with carries, their adjoints), the four scans follow back to back.
+ * w[l], z[l], dw[l], carry[l] (NULL or four buffers of ifl_carry_bytes) are host arrays of four device pointers.
+ * ifl_unit_backward_f32: dx = dL/dx and dw[l] = dL/dw[l] from gout = dL/dz[3] (BR -> BL -> TR -> TL).
+ * Workspace: ifl_unit_workspace_bytes(IFL_OP_INVERSE / IFL_OP_BACKWARD, ...).
+ */
+size_t ifl_unit_workspace_bytes(int op, int B, int C, int H, int W, int KH, int KW, unsigned flags);
+int ifl_unit_inverse_f32(const float *x, const float *const w[4], float *const z[4], int B, int C, int H, int W,
+                         int KH, int KW, unsigned flags, void *ws, size_t ws_bytes, void *const carry[4],
+                         ifl_stream_t stream);
+int ifl_unit_backward_f32(const float *gout, const float *const z[4], const float *const w[4], float *dx,
+                          float *const dw[4], int B, int C, int H, int W, int KH, int KW, unsigned flags, void *ws,
+                          size_t ws_bytes, void *const carry[4], ifl_stream_t stream);
+
+/*
  * Weight gradient from a precomputed dx:  dw = -(sum dx (x) shifted z) * mask.
  * Second half of inv_conv_with_bp.dw (inv_conv_with_bp_general.cpp:99-112).
  */

@@ -403,6 +403,102 @@ int ifl_backward_f32(const float *gout, const float *z, const float *x, const fl
     }
 }
 
+// ---- the inverse-flow block: TL -> TR -> BL -> BR (inf/layers/inv_flow.py:13-53) ------------------------------
+
+static const int kUnitOrder[4] = {IFL_ORDER_TL, IFL_ORDER_TR, IFL_ORDER_BL, IFL_ORDER_BR};
+
+size_t ifl_unit_workspace_bytes(int op, int B, int C, int H, int W, int KH, int KW, unsigned flags)
+{
+    if (op == IFL_OP_INVERSE) return 4 * ifl_workspace_bytes(IFL_OP_INVERSE, B, C, H, W, KH, KW, flags) + 1024;
+    if (op == IFL_OP_BACKWARD) {
+        const size_t n = align_up((size_t)(B < 0 ? 0 : B) * C * H * W * sizeof(float), 256) + 256;
+        return ifl_workspace_bytes(IFL_OP_BACKWARD, B, C, H, W, KH, KW, flags) + 2 * n + 1024;
+    }
+    return 0;
+}
+
+int ifl_unit_inverse_f32(const float *x, const float *const w[4], float *const z[4], int B, int C, int H, int W, int KH,
+                         int KW, unsigned flags, void *ws, size_t ws_bytes, void *const carry[4], ifl_stream_t stream)
+{
+    clear_error();
+    int rc = check_shape("ifl_unit_inverse_f32", B, C, H, W, KH, KW, IFL_ORDER_TL);
+    if (rc) return rc;
+    if (B == 0) return IFL_OK;
+    if (!x || !w || !z) IFL_FAIL(IFL_EINVAL, "ifl_unit_inverse_f32: null pointer");
+    for (int l = 0; l < 4; ++l)
+        if (!w[l] || !z[l]) IFL_FAIL(IFL_EINVAL, "ifl_unit_inverse_f32: null tensor pointer (layer %d)", l);
+    hipStream_t s = (hipStream_t)stream;
+    const float *in[4] = {x, z[0], z[1], z[2]};
+    Geom g[4];
+    bool mfma = !(flags & (IFL_FLAG_NO_MFMA | IFL_FLAG_EXACT_F32));
+    for (int l = 0; l < 4; ++l) {
+        g[l] = make_geom(B, C, H, W, KH, KW, kUnitOrder[l], flags);
+        mfma = mfma && scan_mfma_supported(g[l], in[l], z[l]);
+    }
+    const size_t per = ifl_workspace_bytes(IFL_OP_INVERSE, B, C, H, W, KH, KW, flags);
+    if (!mfma) {
+        // shapes the MFMA scan does not cover: the four layers one after the other
+        if (ws_bytes < 4 * per) IFL_FAIL(IFL_EWORKSPACE, "ifl_unit_inverse_f32: workspace too small: need %zu bytes, have %zu", 4 * per, ws_bytes);
+        for (int l = 0; l < 4; ++l)
+            if ((rc = ifl_inverse_f32(in[l], w[l], z[l], B, C, H, W, KH, KW, kUnitOrder[l], flags, (char *)ws + l * per,
+                                      per, carry ? carry[l] : nullptr, stream)))
+                return rc;
+        return IFL_OK;
+    }
+    // one fold launch for the four layers (and, with carries, their adjoints), then the four scans back to back
+    Carver cv(ws, ws_bytes);
+    FoldJobs jobs;
+    float *wf[4], *wf2[4];
+    int *ovf[4];
+    CarryView co[4];
+    const bool with_carry = carry && carry[0] && carry[1] && carry[2] && carry[3];
+    for (int l = 0; l < 4; ++l) {
+        (void)cv.take<double>((size_t)C * C);
+        wf[l] = cv.take<float>((size_t)KH * KW * C * C);
+        wf2[l] = cv.take<float>((size_t)KH * KW * C * C);
+        ovf[l] = cv.take<int>((size_t)B + 1);
+        co[l] = CarryView{};
+        if (with_carry) co[l] = carry_view(carry[l], C, KH, KW);
+        jobs.job[l] = FoldJob{w[l], wf[l], wf2[l], co[l].adj_pack, co[l].adj_wf32, g[l], 0, co[l].zmax, co[l].dxmax};
+    }
+    if (!cv.ok()) IFL_FAIL(IFL_EWORKSPACE, "ifl_unit_inverse_f32: workspace too small: need %zu bytes, have %zu", cv.off, cv.cap);
+    {
+        ProfScope ps(IFL_PROF_FOLD, s);
+        if ((rc = launch_foldpack_jobs(jobs, 4, with_carry ? 2 : 1, s))) return rc;
+    }
+    for (int l = 0; l < 4; ++l) {
+        ProfScope ps(IFL_PROF_SCAN, s);
+        if ((rc = launch_scan_mfma(in[l], wf[l], z[l], g[l], g[l].flipH, g[l].flipW, ovf[l], wf2[l], co[l].zmax, s))) return rc;
+    }
+    return IFL_OK;
+}
+
+int ifl_unit_backward_f32(const float *gout, const float *const z[4], const float *const w[4], float *dx, float *const dw[4],
+                          int B, int C, int H, int W, int KH, int KW, unsigned flags, void *ws, size_t ws_bytes,
+                          void *const carry[4], ifl_stream_t stream)
+{
+    clear_error();
+    int rc = check_shape("ifl_unit_backward_f32", B, C, H, W, KH, KW, IFL_ORDER_TL);
+    if (rc) return rc;
+    if (!gout || !z || !w || !dx || !dw) IFL_FAIL(IFL_EINVAL, "ifl_unit_backward_f32: null pointer");
+    const size_t n = (size_t)B * C * H * W;
+    Carver cv(ws, ws_bytes);
+    float *t0 = cv.take<float>(n), *t1 = cv.take<float>(n);
+    if (!cv.ok()) IFL_FAIL(IFL_EWORKSPACE, "ifl_unit_backward_f32: workspace too small: need %zu bytes, have %zu", cv.off, cv.cap);
+    void *rest = (char *)ws + align_up(cv.off, 256);
+    const size_t rest_bytes = ws_bytes > align_up(cv.off, 256) ? ws_bytes - align_up(cv.off, 256) : 0;
+    // BR -> BL -> TR -> TL: the gradient w.r.t. a layer's input is the next one's output gradient
+    const float *gcur = gout;
+    for (int l = 3; l >= 0; --l) {
+        float *gnext = l == 0 ? dx : ((l & 1) ? t0 : t1);
+        if ((rc = ifl_backward_f32(gcur, z[l], nullptr, w[l], gnext, dw[l], 0.0f, nullptr, B, C, H, W, KH, KW, kUnitOrder[l],
+                                   flags, rest, rest_bytes, carry ? carry[l] : nullptr, stream)))
+            return rc;
+        gcur = gnext;
+    }
+    return IFL_OK;
+}
+
 // ---- SelfNormConv pieces -------------------------------------------------------------------
 
 static int check_conv(const char *fn, int B, int Ci, int Co, int H, int W, int KH, int KW, int ph, int pw)

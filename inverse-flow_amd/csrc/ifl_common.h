@@ -72,6 +72,21 @@ size_t scan_mfma_pack_bytes(const Geom &g);
 // out1/wf1 in one launch.  zero0/zero1: optional words cleared by the launch (absmax accumulators).
 int launch_foldpack_mfma(const float *w, void *out0, float *wf0, void *out1, float *wf1, const Geom &g, int transposed,
                          int ndir, unsigned *zero0, unsigned *zero1, hipStream_t s);
+// the same for up to four layers (an inverse-flow block, inf/layers/inv_flow.py:13-53) in ONE launch
+struct FoldJob {
+    const float *w;
+    void *out0;
+    float *wf0;
+    void *out1;
+    float *wf1;
+    Geom g;
+    int transposed;
+    unsigned *zero0, *zero1;
+};
+struct FoldJobs {
+    FoldJob job[4];
+};
+int launch_foldpack_jobs(const FoldJobs &jobs, int njobs, int ndir, hipStream_t s);
 // amax: optional device word that receives max|z| (atomicMax of float bits; must be cleared beforehand)
 int launch_scan_mfma(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, int *flags,
                      const float *wf32, unsigned *amax, hipStream_t s);

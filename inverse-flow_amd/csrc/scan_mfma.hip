@@ -726,12 +726,16 @@ __device__ __forceinline__ size_t w_index2(int co, int ci, int dh, int dw, int C
     return (((size_t)co * C + ci) * KH + kh) * KW + kw;
 }
 
-template <int C>
-__global__ __launch_bounds__(256) void k_foldpack(const float *__restrict__ w, _Float16 *__restrict__ apack0,
-                                                  float *__restrict__ wf0, _Float16 *__restrict__ apack1,
-                                                  float *__restrict__ wf1, Geom g, int transposed0,
-                                                  unsigned *__restrict__ zero0, unsigned *__restrict__ zero1)
+template <int C> __global__ __launch_bounds__(256) void k_foldpack(FoldJobs jobs)
 {
+    // blockIdx.z = layer of an inverse-flow block (1 for a single layer)
+    const FoldJob &job = jobs.job[blockIdx.z];
+    const float *__restrict__ w = job.w;
+    _Float16 *apack0 = (_Float16 *)job.out0, *apack1 = (_Float16 *)job.out1;
+    float *wf0 = job.wf0, *wf1 = job.wf1;
+    const Geom g = job.g;
+    const int transposed0 = job.transposed;
+    unsigned *zero0 = job.zero0, *zero1 = job.zero1;
     // blockIdx.y = 0: direction `transposed0`; blockIdx.y = 1: the other direction (forward call that also
     // prepares the adjoint for the backward).  Runs ahead of the scans on the stream: clears their absmax words.
     const int transposed = blockIdx.y == 0 ? transposed0 : 1 - transposed0;
@@ -894,7 +898,7 @@ __global__ __launch_bounds__(256) void k_foldpack(const float *__restrict__ w, _
     }
     IFL_FSTAMP(); // 3: product + pack
 #ifdef IFL_STAMPS
-    if (g_stamps && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+    if (g_stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0)
         for (int k = 0; k < 4; ++k) g_stamps[72 + k] = ft[k];
 #endif
 }
@@ -910,20 +914,26 @@ bool scan_mfma_supported(const Geom &g, const void *x, const void *z)
     return true;
 }
 
-int launch_foldpack_mfma(const float *w, void *out0, float *wf0, void *out1, float *wf1, const Geom &g, int transposed,
-                         int ndir, unsigned *zero0, unsigned *zero1, hipStream_t s)
+int launch_foldpack_jobs(const FoldJobs &jobs, int njobs, int ndir, hipStream_t s)
 {
-    const dim3 grid(g.KH * g.KW * (g.C / 16), ndir);
+    const Geom &g = jobs.job[0].g; // (all layers of a block share C, KH, KW)
+    const dim3 grid(g.KH * g.KW * (g.C / 16), ndir, njobs);
     if (g.C == 64)
-        hipLaunchKernelGGL(k_foldpack<64>, grid, dim3(256), 0, s, w, (_Float16 *)out0, wf0, (_Float16 *)out1, wf1, g,
-                           transposed, zero0, zero1);
+        hipLaunchKernelGGL(k_foldpack<64>, grid, dim3(256), 0, s, jobs);
     else if (g.C == 32)
-        hipLaunchKernelGGL(k_foldpack<32>, grid, dim3(256), 0, s, w, (_Float16 *)out0, wf0, (_Float16 *)out1, wf1, g,
-                           transposed, zero0, zero1);
+        hipLaunchKernelGGL(k_foldpack<32>, grid, dim3(256), 0, s, jobs);
     else
         IFL_FAIL(IFL_EUNSUPPORTED, "launch_foldpack_mfma: C=%d", g.C);
     IFL_HIP(hipGetLastError());
     return IFL_OK;
+}
+
+int launch_foldpack_mfma(const float *w, void *out0, float *wf0, void *out1, float *wf1, const Geom &g, int transposed,
+                         int ndir, unsigned *zero0, unsigned *zero1, hipStream_t s)
+{
+    FoldJobs jobs;
+    jobs.job[0] = FoldJob{w, out0, wf0, out1, wf1, g, transposed, zero0, zero1};
+    return launch_foldpack_jobs(jobs, 1, ndir, s);
 }
 
 template <int C, int KH, int KW, int NTILE>

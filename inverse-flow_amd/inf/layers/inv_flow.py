@@ -1,8 +1,39 @@
 """The full "inverse flow" block: TL -> TR -> BL -> BR chain of inverse-conv layers
-(reference: inf/layers/inv_flow.py:13-53)."""
+(reference: inf/layers/inv_flow.py:13-53).
+
+The forward runs as ONE library call (ifl_unit_inverse_f32: a single fold launch for the four layers and their
+adjoints, then the four scans back to back), the backward as one call as well (ifl_unit_backward_f32); `reverse`
+walks the layers like the reference."""
+import torch
 import torch.nn as nn
 
+import invflow_hip as _h
+
 from .inv_conv import inv_flow_with_pad
+
+
+class _unit_fn(torch.autograd.Function):
+    """z_BR = A_BR^-1 A_BL^-1 A_TR^-1 A_TL^-1 x with the true gradients of x and of the four kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w_tl, w_tr, w_bl, w_br, flags=0):
+        x = x.contiguous()
+        ws4 = [w.contiguous() for w in (w_tl, w_tr, w_bl, w_br)]
+        need_bwd = any(ctx.needs_input_grad[:5])
+        carries = [_h.new_carry(w) for w in ws4] if need_bwd else None
+        zs = _h.unit_inverse(x, ws4, flags, carries)
+        ctx.flags, ctx.carries = flags, carries
+        ctx.versions = [w._version for w in ws4]
+        ctx.save_for_backward(*ws4, *zs)
+        return zs[3]
+
+    @staticmethod
+    def backward(ctx, output_grad):
+        saved = ctx.saved_tensors
+        ws4, zs = list(saved[:4]), list(saved[4:])
+        fresh = all(w._version == v for w, v in zip(ws4, ctx.versions))
+        dx, dws = _h.unit_backward(output_grad.contiguous(), zs, ws4, ctx.flags, ctx.carries if fresh else None)
+        return (dx, *dws, None)
 
 
 class Inv_FlowUnit(nn.Module):
@@ -20,8 +51,15 @@ class Inv_FlowUnit(nn.Module):
         return (self.conv_tl, self.conv_tr, self.conv_bl, self.conv_br)
 
     def forward(self, x, context=None):
+        layers = self._chain()
+        flags = layers[0].flags
+        # one library call for the block when the four layers agree on their flags and have the unit diagonal
+        # (log-det exactly 0, inv_conv.py:221); otherwise layer by layer like the reference
+        if all(l.flags == flags for l in layers) and not (flags & _h.FLAG_GENERAL_DIAG) and x.is_cuda:
+            out = _unit_fn.apply(x, *(l.weight_fwd for l in layers), flags)
+            return out, 0.0
         logdet = 0.0
-        for layer in self._chain():
+        for layer in layers:
             x, ld = layer(x, context)
             logdet = logdet + ld
         return x, logdet

@@ -31,6 +31,9 @@ SIGNATURES = {
     "ifl_profile_collect": (_i, [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i)]),
     "ifl_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _u]),
     "ifl_inverse_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp]),
+    "ifl_unit_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _u]),
+    "ifl_unit_inverse_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp]),
+    "ifl_unit_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp]),
     "ifl_carry_bytes": (_sz, [_i, _i, _i]),
     "ifl_forward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "ifl_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp]),
@@ -157,6 +160,58 @@ def inverse(x, w, order="TL", flags=0, out=None, carry=None):
                                _ptr(carry), torch.cuda.current_stream().cuda_stream)
     _check(rc, "ifl_inverse_f32")
     return out
+
+
+def _ptr4(ts):
+    """host array of four device pointers (NULL entries for None)"""
+    arr = (ctypes.c_void_p * 4)()
+    for i, t in enumerate(ts):
+        arr[i] = _ptr(t)
+    return arr
+
+
+def unit_inverse(x, ws4, flags=0, carries=None):
+    """The inverse-flow block TL -> TR -> BL -> BR (inf/layers/inv_flow.py:13-53): returns the four layer outputs
+    [z_TL, z_TR, z_BL, z_BR]; one fold launch for the four layers (ifl_unit_inverse_f32)."""
+    _chk_tensor(x, "input")
+    if len(ws4) != 4:
+        raise RuntimeError("unit_inverse needs four kernels (TL, TR, BL, BR)")
+    for w in ws4:
+        _chk_tensor(w, "kernel")
+    B, C, H, W, KH, KW = _shape5(x, ws4[0])
+    for w in ws4[1:]:
+        if tuple(w.shape) != tuple(ws4[0].shape):
+            raise RuntimeError("the four kernels of a block must have one shape")
+    dev = _same_device(x, *ws4)
+    zs = [torch.empty_like(x) for _ in range(4)]
+    L = lib()
+    with torch.cuda.device(dev):
+        nb = L.ifl_unit_workspace_bytes(OP_INVERSE, B, C, H, W, KH, KW, flags)
+        ws = _ws(nb, dev)
+        wp, zp = _ptr4(ws4), _ptr4(zs)
+        cp = _ptr4(carries) if carries is not None else None
+        rc = L.ifl_unit_inverse_f32(_ptr(x), wp, zp, B, C, H, W, KH, KW, flags, _ptr(ws), nb, cp,
+                                    torch.cuda.current_stream().cuda_stream)
+    _check(rc, "ifl_unit_inverse_f32")
+    return zs
+
+
+def unit_backward(g, zs, ws4, flags=0, carries=None):
+    """dL/dx and [dL/dw_TL, .., dL/dw_BR] of the block from g = dL/dz_BR (ifl_unit_backward_f32)."""
+    _chk_tensor(g, "grad_output")
+    B, C, H, W, KH, KW = _shape5(g, ws4[0])
+    dev = _same_device(g, *zs, *ws4)
+    dx = torch.empty_like(g)
+    dws = [torch.empty_like(w) for w in ws4]
+    L = lib()
+    with torch.cuda.device(dev):
+        nb = L.ifl_unit_workspace_bytes(OP_BACKWARD, B, C, H, W, KH, KW, flags)
+        ws = _ws(nb, dev)
+        cp = _ptr4(carries) if carries is not None else None
+        rc = L.ifl_unit_backward_f32(_ptr(g), _ptr4(zs), _ptr4(ws4), _ptr(dx), _ptr4(dws), B, C, H, W, KH, KW, flags,
+                                     _ptr(ws), nb, cp, torch.cuda.current_stream().cuda_stream)
+    _check(rc, "ifl_unit_backward_f32")
+    return dx, dws
 
 
 def forward(z, w, order="TL", flags=0, out=None, want_logdet=False):

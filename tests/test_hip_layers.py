@@ -182,3 +182,46 @@ def test_selfnorm_layer_recon_and_exact(H, sym):
     xf = torch.randn(5, 12, device="cuda")
     of, ldf = fc(xf, compute_expensive=True)
     np.testing.assert_allclose(host(fc.reverse(of, compute_expensive=True)), host(xf), atol=1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 64, 32, 32, 3), (2, 32, 16, 16, 3), (2, 64, 16, 16, 2), (2, 6, 9, 5, 3)],
+                         ids=lambda s_: "b%dc%d_%dx%d_k%d" % s_)
+def test_flow_unit_fused_block(H, shape):
+    """Inv_FlowUnit (inf/layers/inv_flow.py:13-53) as one library call (ifl_unit_inverse_f32 / ifl_unit_backward_f32):
+    same outputs and gradients as the four layers called one after the other (bitwise on the MFMA path: the same
+    kernels run on the same data), and the oracle's chain within the tolerance."""
+    from inf.layers.inv_flow import Inv_FlowUnit
+    from oracle import oracle as O
+    B, C, Hh, Ww, K = shape
+    torch.manual_seed(3)
+    unit = Inv_FlowUnit(C, C, (K, K)).cuda()
+    x = torch.randn(B, C, Hh, Ww, device="cuda", requires_grad=True)
+    g = torch.randn(B, C, Hh, Ww, device="cuda")
+    out, ld = unit(x)
+    assert ld == 0.0
+    out.backward(g)
+    dx_f = x.grad.clone()
+    dws_f = [l.weight_fwd.grad.clone() for l in unit._chain()]
+    # layer by layer
+    x2 = x.detach().clone().requires_grad_(True)
+    for l in unit._chain():
+        l.weight_fwd.grad = None
+    h = x2
+    for l in unit._chain():
+        h, _ = l(h)
+    h.backward(g)
+    assert torch.equal(out, h)
+    assert torch.equal(dx_f, x2.grad)
+    for a, l in zip(dws_f, unit._chain()):
+        assert torch.equal(a, l.weight_fwd.grad)
+    # oracle chain (fp64)
+    z = x.detach().cpu().double().numpy()
+    for l in unit._chain():
+        z = O.inverse(z, l.weight_fwd.detach().cpu().double().numpy(), 0, l.order, nthreads=8)
+    rel = float(np.linalg.norm(out.detach().cpu().double().numpy() - z) / np.linalg.norm(z))
+    assert rel < 1e-5
+    # round trip through reverse: four layers whose init (identity on the center tap, inv_conv.py:153-165) grows z along
+    # each sweep, so the fp32 round trip carries the chain's conditioning (1.8e-3 at C=64, 32x32)
+    back = unit.reverse(out.detach())
+    assert float((back - x.detach()).norm() / x.detach().norm()) < 1e-2

@@ -84,9 +84,13 @@ static int check_shape(const char *fn, int B, int C, int H, int W, int KH, int K
     return IFL_OK;
 }
 
+// buffers that may hold MFMA-packed weights are sized for the padded channel count (scan_mfma.hip)
+static size_t cpad(int C) { return C <= 64 ? (size_t)mfma_padded_channels(C) : (size_t)C; }
+
 static size_t fold_bytes(int B, int C, int KH, int KW)
 {
-    return align_up((size_t)C * C * sizeof(double), 256) + 2 * align_up((size_t)KH * KW * C * C * sizeof(float), 256) +
+    const size_t cp = cpad(C);
+    return align_up(cp * cp * sizeof(double), 256) + 2 * align_up((size_t)KH * KW * cp * cp * sizeof(float), 256) +
            align_up(((size_t)B + 1) * sizeof(int), 256) + 1024;
 }
 
@@ -115,7 +119,8 @@ struct CarryView {
 };
 static size_t carry_bytes(int C, int KH, int KW)
 {
-    return 256 + 2 * align_up((size_t)KH * KW * C * C * sizeof(float), 256);
+    const size_t cp = cpad(C);
+    return 256 + 2 * align_up((size_t)KH * KW * cp * cp * sizeof(float), 256);
 }
 static CarryView carry_view(void *carry, int C, int KH, int KW)
 {
@@ -124,7 +129,7 @@ static CarryView carry_view(void *carry, int C, int KH, int KW)
     v.zmax = (unsigned *)p;
     v.dxmax = (unsigned *)(p + 64);
     v.adj_pack = p + 256;
-    v.adj_wf32 = (float *)(p + 256 + align_up((size_t)KH * KW * C * C * sizeof(float), 256));
+    v.adj_wf32 = (float *)(p + 256 + align_up((size_t)KH * KW * cpad(C) * cpad(C) * sizeof(float), 256));
     return v;
 }
 // the carry is used iff the *shape* can take the MFMA scan: both calls evaluate this on the host
@@ -141,9 +146,10 @@ static bool carry_usable(const Geom &g, unsigned flags)
 static int run_scan(const float *x, const float *w, float *z, const Geom &g, int transposed, unsigned flags,
                     Carver &cv, void *carry_out, void *carry_in, bool *amax_valid, hipStream_t s)
 {
-    double *linv = cv.take<double>((size_t)g.C * g.C);
-    float *wf = cv.take<float>((size_t)g.KH * g.KW * g.C * g.C); // folded taps (fp32) or packed fp16 hi/lo fragments
-    float *wf2 = cv.take<float>((size_t)g.KH * g.KW * g.C * g.C); // fp32 copy of the folded taps (in-kernel fp32 redo)
+    const size_t cp = cpad(g.C);
+    double *linv = cv.take<double>(cp * cp);
+    float *wf = cv.take<float>((size_t)g.KH * g.KW * cp * cp); // folded taps (fp32) or packed fp16 hi/lo fragments
+    float *wf2 = cv.take<float>((size_t)g.KH * g.KW * cp * cp); // fp32 copy of the folded taps (in-kernel fp32 redo)
     int *ovf = cv.take<int>((size_t)g.B + 1);                    // per-image overflow flags of the MFMA scan
     if (!cv.ok()) IFL_FAIL(IFL_EWORKSPACE, "workspace too small: need %zu bytes, have %zu", cv.off, cv.cap);
     int rc;
@@ -453,9 +459,9 @@ int ifl_unit_inverse_f32(const float *x, const float *const w[4], float *const z
     CarryView co[4];
     const bool with_carry = carry && carry[0] && carry[1] && carry[2] && carry[3];
     for (int l = 0; l < 4; ++l) {
-        (void)cv.take<double>((size_t)C * C);
-        wf[l] = cv.take<float>((size_t)KH * KW * C * C);
-        wf2[l] = cv.take<float>((size_t)KH * KW * C * C);
+        (void)cv.take<double>(cpad(C) * cpad(C));
+        wf[l] = cv.take<float>((size_t)KH * KW * cpad(C) * cpad(C));
+        wf2[l] = cv.take<float>((size_t)KH * KW * cpad(C) * cpad(C));
         ovf[l] = cv.take<int>((size_t)B + 1);
         co[l] = CarryView{};
         if (with_carry) co[l] = carry_view(carry[l], C, KH, KW);

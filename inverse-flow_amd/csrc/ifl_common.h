@@ -63,7 +63,8 @@ int launch_flip_kernel(const float *w, float *wt, int Co, int Ci, int KH, int KW
 int launch_recon_mix(const float *dx, const float *x, const float *az, float *t, float coef, float *loss,
                      float loss_scale, size_t n, hipStream_t s);
 
-// ---- MFMA scan (scan_mfma.hip): C in {32,64}, K in {2x2,3x3}, H <= 32, W % 4 == 0 -----------------
+// ---- MFMA scan (scan_mfma.hip): 9 <= C <= 64 (padded to 32 / 64), K in {2x2,3x3}, H <= 32, W % 4 == 0 ---------
+int mfma_padded_channels(int C); // 32 or 64: what the MFMA kernels are instantiated for
 bool scan_mfma_supported(const Geom &g, const void *x, const void *z);
 size_t scan_mfma_pack_bytes(const Geom &g);
 // mode 0: packed split-fp16 A fragments of the right fold (also zeroes the B overflow flags + the any-flag);

@@ -96,7 +96,9 @@ __device__ unsigned long long *g_stamps = nullptr;
     } while (0)
 #endif
 
-template <int C, int KH, int KW, int NTILE>
+// PAD: the layer has fewer channels than the instantiation (geom.C < C; the weights are padded with the identity by
+// k_foldpack): lanes beyond geom.C move nothing, their x staging is zero.
+template <int C, int KH, int KW, int NTILE, bool PAD>
 __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__restrict__ xin,
                                                                     float *__restrict__ zout,
                                                                     const half8 *__restrict__ apack, int H, int W,
@@ -122,6 +124,9 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
     {
         const floatx4 zz = {0.f, 0.f, 0.f, 0.f};
         for (int i = tid * 16; i < Cfg::RINGB; i += Cfg::THREADS * 16) *(floatx4 *)(lds + i) = zz;
+        // padded channels are never loaded: their x staging must read as zero (finite times a zero weight)
+        if (PAD)
+            for (int i = Cfg::OFF_XS + tid * 16; i < Cfg::OFF_ZQ; i += Cfg::THREADS * 16) *(floatx4 *)(lds + i) = zz;
     }
 
     // ---- folded weights -> registers (A fragments, hi and lo) -----------------------------------
@@ -158,10 +163,13 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
     }
 
     // DMA / store role: lane = channel, G rows per wave and step
-    const int cl = lane < C ? lane : 0;
+    const int Cr = PAD ? geom.C : C; // channels of the layer
+    const int cl = lane < Cr ? lane : 0;
+    // lanes that move data, as an EXEC mask (PAD: row operations are issued under it)
+    const unsigned long long lmask = PAD ? __builtin_amdgcn_ballot_w64(lane < Cr) : ~0ull;
     const unsigned voff = (unsigned)((size_t)cl * H * W * sizeof(float)); // per-lane byte offset of its channel
-    const char *xg = (const char *)xin + (size_t)b * C * H * W * sizeof(float);
-    char *zg = (char *)zout + (size_t)b * C * H * W * sizeof(float);
+    const char *xg = (const char *)xin + (size_t)b * Cr * H * W * sizeof(float);
+    char *zg = (char *)zout + (size_t)b * Cr * H * W * sizeof(float);
     // Row operations of a step (G DMAs of x quads, G stores of z quads) are wave-uniform, but scalar arithmetic is
     // the most expensive thing a lone wave can issue (measured: 8.4 cycles per SALU instruction, 5.3 per VALU,
     // tools/issue_rate_probe.hip).  Lane j < 2G therefore computes operation j's addresses with vector
@@ -385,9 +393,9 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
             for (int i = 0; i < G; ++i) {
                 char *dstp = ro_ptr(G + i); // wave-uniform: the quad's place in z
                 const unsigned okm = (unsigned)__builtin_amdgcn_readlane(ro_okm, G + i);
-                const unsigned long long em = ((unsigned long long)okm << 32) | okm;
+                const unsigned long long em = (((unsigned long long)okm << 32) | okm) & lmask;
                 unsigned long long saved;
-                if (C == 64 || lane < C) {
+                if (C == 64 || PAD || lane < C) {
                     asm volatile("s_mov_b64 %0, exec\n\t"
                                  "s_and_b64 exec, exec, %1\n\t"
                                  "global_store_dwordx4 %2, %3, %4\n\t"
@@ -396,6 +404,7 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
                                  : "=&s"(saved)
                                  : "s"(em), "v"(voff), "v"(sv[i]), "s"(dstp)
                                  : "memory", "scc");
+                    // (padded lanes hold channel 0's quad again: harmless for the maximum)
                     const float m = fmaxf(fmaxf(fabsf(sv[i][0]), fabsf(sv[i][1])), fmaxf(fabsf(sv[i][2]), fabsf(sv[i][3])));
                     zmax = fmaxf(zmax, __uint_as_float(__float_as_uint(m) & okm));
                 }
@@ -405,9 +414,22 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
         auto chunk_dma = [&](int i) {
             const char *src = ro_ptr(i); // wave-uniform: the quad, or the image's first one when none is due
             const unsigned dst = (unsigned)__builtin_amdgcn_readlane(ro_loff, i); // lane c lands at +16c
-            if (C == 64 || lane < C)
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + voff),
-                                                 (void __attribute__((address_space(3))) *)(size_t)dst, 16, 0, 0);
+            if constexpr (!PAD) {
+                if (C == 64 || lane < C)
+                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + voff),
+                                                     (void __attribute__((address_space(3))) *)(size_t)dst, 16, 0, 0);
+            } else {
+                // the same LDS-DMA under the lane mask (padded channels must stay zero in the staging area)
+                unsigned long long saved;
+                asm volatile("s_mov_b32 m0, %1\n\t"
+                             "s_mov_b64 %0, exec\n\t"
+                             "s_and_b64 exec, exec, %2\n\t"
+                             "global_load_lds_dwordx4 %3, %4\n\t"
+                             "s_mov_b64 exec, %0"
+                             : "=&s"(saved)
+                             : "s"(dst), "s"(lmask), "v"(voff), "s"(src)
+                             : "memory", "scc", "m0");
+            }
         };
         // ---- chunk: epilogue of tile T (the chain): r_d = x + acc[0] -> split fp16 -> ring; then the accumulators
         //      rotate: diagonal d+1 becomes the head, a fresh one joins for d+3 -------------------------------
@@ -693,9 +715,9 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
         scan_general_body<Cfg::THREADS>(xin, wf32, zout, geom, rh, rw, 1, (float *)lds, b, tid);
         if (amax) { // the quads stored above are void: take the maximum of what the redo wrote
             __syncthreads();
-            const float *zi = zout + (size_t)b * C * H * W;
+            const float *zi = zout + (size_t)b * Cr * H * W;
             zmax = 0.f;
-            for (int i = tid; i < C * H * W; i += Cfg::THREADS) zmax = fmaxf(zmax, fabsf(zi[i]));
+            for (int i = tid; i < Cr * H * W; i += Cfg::THREADS) zmax = fmaxf(zmax, fabsf(zi[i]));
         }
     }
     if (amax) {
@@ -776,23 +798,29 @@ template <int C> __global__ __launch_bounds__(256) void k_foldpack(FoldJobs jobs
     // ~20 exposed memory latencies: 15.8k of the kernel's 41k cycles).
     {
         constexpr int NL = C * C / 256, NWL = 16 * C / 256;
+        const int Cr = g.C; // channels of the layer (<= C: the rest is padding, identity in L and zero in W_t)
         float vl[NL], vw[NWL > 0 ? NWL : 1];
 #pragma unroll
         for (int u = 0; u < NL; ++u) {
             const int idx = tid + 256 * u, i = idx / C, k = idx % C;
-            vl[u] = w[w_index2(i, k, 0, 0, C, g.KH, g.KW, g.flipH, g.flipW)];
+            const bool in = i < Cr && k < Cr;
+            vl[u] = w[w_index2(in ? i : 0, in ? k : 0, 0, 0, Cr, g.KH, g.KW, g.flipH, g.flipW)];
         }
         const int t = s < NT - 1 ? s + 1 : 1 % (NT > 1 ? NT : 2), dh = t / g.KW, dw = t % g.KW; // (last slot: a valid tap, unused)
 #pragma unroll
         for (int u = 0; u < NWL; ++u) {
             const int idx = tid + 256 * u, cl = idx / C, m = idx % C, c = 16 * rgrp + cl;
-            vw[u] = transposed ? w[w_index2(m, c, NT > 1 ? dh : 0, NT > 1 ? dw : 0, C, g.KH, g.KW, g.flipH, g.flipW)]
-                               : w[w_index2(c, m, NT > 1 ? dh : 0, NT > 1 ? dw : 0, C, g.KH, g.KW, g.flipH, g.flipW)];
+            const bool in = c < Cr && m < Cr;
+            const int cc = in ? c : 0, mm = in ? m : 0;
+            const float v = transposed ? w[w_index2(mm, cc, NT > 1 ? dh : 0, NT > 1 ? dw : 0, Cr, g.KH, g.KW, g.flipH, g.flipW)]
+                                       : w[w_index2(cc, mm, NT > 1 ? dh : 0, NT > 1 ? dw : 0, Cr, g.KH, g.KW, g.flipH, g.flipW)];
+            vw[u] = in ? v : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < NL; ++u) {
             const int idx = tid + 256 * u, i = idx / C, k = idx % C;
-            sL[i * LP + k] = k < i ? vl[u] : (k == i ? (g.general_diag ? vl[u] : 1.f) : 0.f);
+            const bool in = i < Cr && k < Cr;
+            sL[i * LP + k] = k < i ? (in ? vl[u] : 0.f) : (k == i ? ((g.general_diag && in) ? vl[u] : 1.f) : 0.f);
         }
         if (s < NT - 1) {
 #pragma unroll
@@ -887,7 +915,8 @@ template <int C> __global__ __launch_bounds__(256) void k_foldpack(FoldJobs jobs
         for (int v = 0; v < 4; ++v) {
             const int cl = 4 * v + lk, c = 16 * rgrp + cl;
             const float val = (float)acc[v];
-            if (wf32) wf32[((size_t)s * C + kc) * C + c] = val; // fp32 copy [slot][kc][c] for the fp32 fallback scan
+            // fp32 copy [slot][kc][c] of the layer's own channels for the fp32 fallback scan
+            if (wf32 && kc < g.C && c < g.C) wf32[((size_t)s * g.C + kc) * g.C + c] = val;
             const _Float16 hi = (_Float16)val;
             const _Float16 lo = (_Float16)((val - (float)hi) * LO_SCALE);
             const int q = kc / 32, gk = (kc % 32) / 8, j = kc % 8;
@@ -903,11 +932,18 @@ template <int C> __global__ __launch_bounds__(256) void k_foldpack(FoldJobs jobs
 #endif
 }
 
-size_t scan_mfma_pack_bytes(const Geom &g) { return (size_t)g.KH * g.KW * g.C * g.C * 2 * sizeof(_Float16); }
+// channel count the MFMA kernels are instantiated for: the layer's own, padded up to 32 or 64
+int mfma_padded_channels(int C) { return C <= 32 ? 32 : 64; }
+
+size_t scan_mfma_pack_bytes(const Geom &g)
+{
+    const size_t ct = (size_t)mfma_padded_channels(g.C);
+    return (size_t)g.KH * g.KW * ct * ct * 2 * sizeof(_Float16);
+}
 
 bool scan_mfma_supported(const Geom &g, const void *x, const void *z)
 {
-    if (!(g.C == 32 || g.C == 64)) return false;
+    if (g.C < 9 || g.C > 64) return false; // (a handful of channels: the VALU scan wins)
     if (!((g.KH == 3 && g.KW == 3) || (g.KH == 2 && g.KW == 2))) return false;
     if (g.W % 4 != 0 || g.H > 32 || g.H < 1) return false;
     if (((uintptr_t)x | (uintptr_t)z) & 15) return false;
@@ -917,13 +953,13 @@ bool scan_mfma_supported(const Geom &g, const void *x, const void *z)
 int launch_foldpack_jobs(const FoldJobs &jobs, int njobs, int ndir, hipStream_t s)
 {
     const Geom &g = jobs.job[0].g; // (all layers of a block share C, KH, KW)
-    const dim3 grid(g.KH * g.KW * (g.C / 16), ndir, njobs);
-    if (g.C == 64)
+    const int ct = mfma_padded_channels(g.C);
+    const dim3 grid(g.KH * g.KW * (ct / 16), ndir, njobs);
+    if (g.C > 64 || g.C < 1) IFL_FAIL(IFL_EUNSUPPORTED, "launch_foldpack_mfma: C=%d", g.C);
+    if (ct == 64)
         hipLaunchKernelGGL(k_foldpack<64>, grid, dim3(256), 0, s, jobs);
-    else if (g.C == 32)
-        hipLaunchKernelGGL(k_foldpack<32>, grid, dim3(256), 0, s, jobs);
     else
-        IFL_FAIL(IFL_EUNSUPPORTED, "launch_foldpack_mfma: C=%d", g.C);
+        hipLaunchKernelGGL(k_foldpack<32>, grid, dim3(256), 0, s, jobs);
     IFL_HIP(hipGetLastError());
     return IFL_OK;
 }
@@ -936,7 +972,7 @@ int launch_foldpack_mfma(const float *w, void *out0, float *wf0, void *out1, flo
     return launch_foldpack_jobs(jobs, 1, ndir, s);
 }
 
-template <int C, int KH, int KW, int NTILE>
+template <int C, int KH, int KW, int NTILE, bool PAD>
 static int launch_one(const float *x, float *z, const void *apack, const Geom &g, int rh, int rw, int *flags,
                       const float *wf32, unsigned *amax, hipStream_t s)
 {
@@ -944,7 +980,7 @@ static int launch_one(const float *x, float *z, const void *apack, const Geom &g
     static_assert(Cfg::LDSB <= 160 * 1024, "ring + x staging must fit the CU's LDS");
     static bool attr_done = false; // idempotent attribute, benign race
     if (!attr_done) {
-        IFL_HIP(hipFuncSetAttribute((const void *)k_scan_mfma<C, KH, KW, NTILE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        IFL_HIP(hipFuncSetAttribute((const void *)k_scan_mfma<C, KH, KW, NTILE, PAD>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     Cfg::LDSB));
         attr_done = true;
     }
@@ -956,7 +992,7 @@ static int launch_one(const float *x, float *z, const void *apack, const Geom &g
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &ptr, sizeof(ptr));
     }
 #endif
-    hipLaunchKernelGGL((k_scan_mfma<C, KH, KW, NTILE>), dim3(g.B), dim3(Cfg::THREADS), Cfg::LDSB, s, x, z,
+    hipLaunchKernelGGL((k_scan_mfma<C, KH, KW, NTILE, PAD>), dim3(g.B), dim3(Cfg::THREADS), Cfg::LDSB, s, x, z,
                        (const half8 *)apack, g.H, g.W, rh, rw, flags, wf32, g, amax);
     IFL_HIP(hipGetLastError());
     return IFL_OK;
@@ -966,8 +1002,11 @@ int launch_scan_mfma(const float *x, const void *apack, float *z, const Geom &g,
                      const float *wf32, unsigned *amax, hipStream_t s)
 {
     const int nt = g.H <= 16 ? 1 : 2;
+    const int ct = mfma_padded_channels(g.C);
 #define IFL_CASE(CC, KK, NN) \
-    if (g.C == CC && g.KH == KK && g.KW == KK && nt == NN) return launch_one<CC, KK, KK, NN>(x, z, apack, g, rh, rw, flags, wf32, amax, s);
+    if (ct == CC && g.KH == KK && g.KW == KK && nt == NN)                                                                   \
+        return g.C == CC ? launch_one<CC, KK, KK, NN, false>(x, z, apack, g, rh, rw, flags, wf32, amax, s)                  \
+                         : launch_one<CC, KK, KK, NN, true>(x, z, apack, g, rh, rw, flags, wf32, amax, s);
     IFL_CASE(64, 3, 1)
     IFL_CASE(64, 3, 2)
     IFL_CASE(32, 3, 1)

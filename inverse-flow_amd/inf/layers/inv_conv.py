@@ -32,10 +32,17 @@ def flip_kernel(W):
     return torch.flip(W, (2, 3)).permute(1, 0, 2, 3).clone()
 
 
+# Inside a torch.autocast region (the reference's bf16 training configs) the arithmetic of these layers stays fp32:
+# tensor arguments are cast to float32 on the way in, gradients come back in float32.
+_fwd32 = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_bwd32 = torch.amp.custom_bwd(device_type="cuda")
+
+
 class inv_conv_(torch.autograd.Function):
     """z = A^-1 x with the true gradients; `order` / `flags` / recon settings are non-tensor args."""
 
     @staticmethod
+    @_fwd32
     def forward(ctx, x, W, order="TL", flags=0, recon_weight=0.0):
         x = x.contiguous()
         Wc = W.contiguous()
@@ -55,6 +62,7 @@ class inv_conv_(torch.autograd.Function):
         return z
 
     @staticmethod
+    @_bwd32
     def backward(ctx, output_grad):
         saved = ctx.saved_tensors
         Wc, z = saved[0], saved[1]

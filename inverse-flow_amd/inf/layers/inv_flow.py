@@ -12,10 +12,17 @@ import invflow_hip as _h
 from .inv_conv import inv_flow_with_pad
 
 
+# Inside a torch.autocast region (the reference's bf16 training configs) the arithmetic of these layers stays fp32:
+# tensor arguments are cast to float32 on the way in, gradients come back in float32.
+_fwd32 = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_bwd32 = torch.amp.custom_bwd(device_type="cuda")
+
+
 class _unit_fn(torch.autograd.Function):
     """z_BR = A_BR^-1 A_BL^-1 A_TR^-1 A_TL^-1 x with the true gradients of x and of the four kernels."""
 
     @staticmethod
+    @_fwd32
     def forward(ctx, x, w_tl, w_tr, w_bl, w_br, flags=0):
         x = x.contiguous()
         ws4 = [w.contiguous() for w in (w_tl, w_tr, w_bl, w_br)]
@@ -28,6 +35,7 @@ class _unit_fn(torch.autograd.Function):
         return zs[3]
 
     @staticmethod
+    @_bwd32
     def backward(ctx, output_grad):
         saved = ctx.saved_tensors
         ws4, zs = list(saved[:4]), list(saved[4:])

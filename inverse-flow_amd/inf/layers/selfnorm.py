@@ -40,10 +40,17 @@ def _compute_weight_multiple(wshape, x, padding):
     return _weight_multiple_host(tuple(wshape), x.shape[2], x.shape[3], tuple(padding)).to(x.device)
 
 
+# Inside a torch.autocast region (the reference's bf16 training configs) the arithmetic of these layers stays fp32:
+# tensor arguments are cast to float32 on the way in, gradients come back in float32.
+_fwd32 = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_bwd32 = torch.amp.custom_bwd(device_type="cuda")
+
+
 class _Conv2dHip(torch.autograd.Function):
     """Plain conv2d with true gradients, all three pieces in HIP (used by add_recon_grad)."""
 
     @staticmethod
+    @_fwd32
     def forward(ctx, x, W, padding):
         x, W = x.contiguous(), W.contiguous()
         ctx.save_for_backward(x, W)
@@ -51,6 +58,7 @@ class _Conv2dHip(torch.autograd.Function):
         return _h.conv2d(x, W, None, padding)
 
     @staticmethod
+    @_bwd32
     def backward(ctx, go):
         x, W = ctx.saved_tensors
         go = go.contiguous()
@@ -65,6 +73,7 @@ def _conv(x, W, padding):
 
 class SelfNormConvFunc(torch.autograd.Function):
     @staticmethod
+    @_fwd32
     def forward(ctx, x, W, bw, R, stride, padding, dilation, groups):
         x, W, R = x.contiguous(), W.contiguous(), R.contiguous()
         z = _h.conv2d(x, W, bw.contiguous() if bw is not None else None, padding)
@@ -73,6 +82,7 @@ class SelfNormConvFunc(torch.autograd.Function):
         return z
 
     @staticmethod
+    @_bwd32
     def backward(ctx, output_grad):
         x, W, bw, R, output = ctx.saved_tensors
         p = ctx.padding

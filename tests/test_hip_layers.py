@@ -225,3 +225,28 @@ def test_flow_unit_fused_block(H, shape):
     # each sweep, so the fp32 round trip carries the chain's conditioning (1.8e-3 at C=64, 32x32)
     back = unit.reverse(out.detach())
     assert float((back - x.detach()).norm() / x.detach().norm()) < 1e-2
+
+
+@pytest.mark.gpu
+def test_layers_inside_autocast(H):
+    """config 2 trains under bf16 autocast: the inverse-conv layer and the block keep their arithmetic in fp32 there
+    (custom_fwd(cast_inputs=float32)) and give the same result as outside the region."""
+    from inf.layers.inv_conv import inv_flow_with_pad
+    from inf.layers.inv_flow import Inv_FlowUnit
+    torch.manual_seed(5)
+    layer = inv_flow_with_pad(32, 32, (3, 3), order="TR").cuda()
+    unit = Inv_FlowUnit(32, 32, (3, 3)).cuda()
+    x = torch.randn(2, 32, 16, 16, device="cuda")
+    ref_l, _ = layer(x)
+    ref_u, _ = unit(x)
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        xb = (x * 1.0)  # stays fp32; a bf16 producer upstream is cast back on entry
+        out_l, _ = layer(xb)
+        out_u, _ = unit(xb.to(torch.bfloat16).float())
+        out_b, _ = layer(x.to(torch.bfloat16))
+    assert out_l.dtype == torch.float32 and torch.equal(out_l, ref_l)
+    assert out_b.dtype == torch.float32
+    ref_b, _ = layer(x.to(torch.bfloat16).float())
+    assert torch.equal(out_b, ref_b)
+    ref_u2, _ = unit(x.to(torch.bfloat16).float())
+    assert torch.equal(out_u, ref_u2)

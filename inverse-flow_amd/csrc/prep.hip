@@ -70,9 +70,62 @@ __global__ __launch_bounds__(256) void k_linv_lds(const float *__restrict__ w, d
     }
 }
 
+// L^-1 for wide layers (C a multiple of 16, e.g. the C = 256 layers of the ImageNet-32 Glow), X kept in global memory:
+// the blocked scheme of k_foldpack (scan_mfma.hip) -- diagonal 16x16 blocks by substitution, one thread per column;
+// off-diagonal blocks one block-distance at a time, X_ij = -X_ii (sum_k L_ik X_kj) on the fp64 matrix cores, one
+// wave per block (layouts: tools/mfma_f64_layout_probe.hip).  One workgroup of 1024 threads; a round's results are
+// published to the other waves by a fence + barrier.  The column-serial kernel above took 4.3 ms at C = 256.
+__global__ __launch_bounds__(1024) void k_linv_blocked(const float *__restrict__ w, double *__restrict__ linv, Geom g)
+{
+    typedef double doublex4 __attribute__((ext_vector_type(4)));
+    const int C = g.C, NBK = C / 16;
+    const int tid = threadIdx.x, wv = tid / 64, lf = tid % 64, li = lf % 16, lk = lf / 16, NWV = blockDim.x / 64;
+    for (int idx = tid; idx < C * C; idx += blockDim.x) linv[idx] = 0.0;
+    __threadfence();
+    __syncthreads();
+    for (int j = tid; j < C; j += blockDim.x) { // diagonal blocks: column j inside its block
+        const int r0 = (j / 16) * 16, jj = j % 16;
+        double col[16];
+#pragma unroll
+        for (int ii = 0; ii < 16; ++ii) {
+            double a0 = (ii == jj) ? 1.0 : 0.0;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+                if (kk < ii && kk >= jj) a0 -= l_entry(w, r0 + ii, r0 + kk, g) * col[kk];
+            col[ii] = ii >= jj ? a0 / l_entry(w, r0 + ii, r0 + ii, g) : 0.0;
+            linv[(size_t)(r0 + ii) * C + j] = col[ii];
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    for (int dist = 1; dist < NBK; ++dist) {
+        const int npairs = NBK - dist;
+        for (int pr = wv; pr < npairs; pr += NWV) { // (wave-uniform trip count per wave)
+            const int bi = pr + dist, bj = pr;
+            doublex4 acc = {0.0, 0.0, 0.0, 0.0};
+            for (int kb = bj; kb < bi; ++kb)
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) {
+                    const int k = 16 * kb + 4 * kc + lk;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(l_entry(w, 16 * bi + li, k, g), linv[(size_t)k * C + 16 * bj + li], acc, 0, 0, 0);
+                }
+            doublex4 res = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) // X_ii is lower triangular: its upper entries are stored zeros
+                res = __builtin_amdgcn_mfma_f64_16x16x4f64(linv[(size_t)(16 * bi + li) * C + 16 * bi + 4 * kc + lk], acc[kc], res, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) linv[(size_t)(16 * bi + 4 * v + lk) * C + 16 * bj + li] = -res[v];
+        }
+        __threadfence(); // this round's blocks are read by other waves in the next one
+        __syncthreads();
+    }
+}
+
 int launch_linv(const float *w, double *linv, const Geom &g, hipStream_t s)
 {
-    if (g.C <= 96) {
+    if (g.C > 96 && g.C % 16 == 0) {
+        hipLaunchKernelGGL(k_linv_blocked, dim3(1), dim3(1024), 0, s, w, linv, g);
+    } else if (g.C <= 96) {
         const size_t lds = (size_t)g.C * g.C * (sizeof(double) + sizeof(float));
         static bool attr_done = false; // idempotent attribute, benign race
         if (!attr_done) {

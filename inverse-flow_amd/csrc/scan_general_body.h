@@ -73,6 +73,9 @@ __device__ __forceinline__ void scan_general_body(const float *__restrict__ xin,
                     }
                     if (!rf) {
                         const float *wt = wf + c;
+                        // (unrolled: the weight loads of 8 k-steps are in flight together; one by one this loop is a chain
+                        // of L2 latencies -- 3.5 ms per scan at C = 256)
+#pragma unroll 8
                         for (int kc = 0; kc < C; ++kc) {
                             const float wv = wt[(size_t)kc * C];
 #pragma unroll
@@ -96,6 +99,7 @@ __device__ __forceinline__ void scan_general_body(const float *__restrict__ xin,
                         if (!any) continue;
                         const float *wt = wf + (size_t)(rf ? t - 1 : t) * C * C + c;
                         const float sgn = rf ? 1.f : -1.f;
+#pragma unroll 8
                         for (int kc = 0; kc < C; ++kc) {
                             const float wv = sgn * wt[(size_t)kc * C];
 #pragma unroll

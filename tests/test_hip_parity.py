@@ -122,6 +122,10 @@ CASES = [
     (2, 64, 16, 16, 2, 2, "0.05", "BR", 0),
     (2, 32, 32, 16, 2, 2, "0.05", "TR", 1),
     (2, 32, 8, 32, 3, 3, "0.05", "TL", 1),
+    (2, 48, 32, 32, 3, 3, "0.02", "BR", 0),   # padded channels on the MFMA scan (48 -> 64, 20 -> 32, 9 -> 32, 33 -> 64)
+    (2, 20, 16, 12, 2, 2, "0.05", "TR", 1),
+    (1, 9, 20, 8, 3, 3, "0.05", "BL", 0),
+    (2, 33, 12, 16, 3, 3, "0.03", "TL", 1),
 ]
 
 

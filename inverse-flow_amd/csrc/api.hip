@@ -188,6 +188,7 @@ static int run_scan(const float *x, const float *w, float *z, const Geom &g, int
         if ((rc = launch_fold(w, linv, wf, g, transposed, s))) return rc;
     }
     ProfScope ps(IFL_PROF_SCAN, s);
+    if (scan_resident_supported(g)) return launch_scan_resident(x, wf, z, g, rh, rw, s);
     return launch_scan_general(x, wf, z, g, rh, rw, s);
 }
 
@@ -252,9 +253,10 @@ size_t ifl_workspace_bytes(int op, int B, int C, int H, int W, int KH, int KW, u
         return wbytes;
     case IFL_OP_BACKWARD:
         // fold + (dx when the caller passes none) + (A z and mixed gradient for the recon term) + dW partials
-        return fold_bytes(B, C, KH, KW) + wbytes + 3 * n + wgrad_mfma_workspace_bytes(B, C, H, KH, KW) + 512;
+        return fold_bytes(B, C, KH, KW) + wbytes + 3 * n + wgrad_mfma_workspace_bytes(B, C, H, KH, KW) +
+               wgrad_small_workspace_bytes(B < 0 ? 0 : B, C, KH, KW) + 512;
     case IFL_OP_DW:
-        return wgrad_mfma_workspace_bytes(B, C, H, KH, KW) + 512;
+        return wgrad_mfma_workspace_bytes(B, C, H, KH, KW) + wgrad_small_workspace_bytes(B < 0 ? 0 : B, C, KH, KW) + 512;
     default:
         return 0;
     }
@@ -333,6 +335,12 @@ static int dw_impl(const float *z, const float *dx, float *dw, int B, int C, int
             return launch_wgrad_mfma(dx, z, dw, wws, B, C, H, W, KH, KW, pt, pl, -1.0f, g.general_diag ? 2 : 1, dkh,
                                      dkw, amax_dx, amax_z, s);
         IFL_FAIL(IFL_EWORKSPACE, "ifl_dw_f32: workspace too small: need %zu bytes, have %zu", cv.off, cv.cap);
+    }
+    if (wgrad_small_supported(B, C, H, W)) {
+        Carver cv(ws, ws_bytes);
+        void *wws = cv.take<char>(wgrad_small_workspace_bytes(B, C, KH, KW));
+        if (cv.ok())
+            return launch_wgrad_small(dx, z, dw, wws, B, C, H, W, KH, KW, pt, pl, -1.0f, g.general_diag ? 2 : 1, dkh, dkw, s);
     }
     return launch_wgrad_direct(dx, z, dw, B, C, C, H, W, H, W, KH, KW, pt, pl, -1.0f, g.general_diag ? 2 : 1, dkh, dkw,
                                s);

@@ -189,6 +189,7 @@ static int run_scan(const float *x, const float *w, float *z, const Geom &g, int
     }
     ProfScope ps(IFL_PROF_SCAN, s);
     if (scan_resident_supported(g)) return launch_scan_resident(x, wf, z, g, rh, rw, s);
+    if (scan_wide_supported(g) && x != z) return launch_scan_wide(x, wf, z, g, rh, rw, s);
     return launch_scan_general(x, wf, z, g, rh, rw, s);
 }
 

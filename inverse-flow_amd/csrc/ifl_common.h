@@ -117,6 +117,10 @@ size_t wgrad_small_workspace_bytes(int B, int C, int KH, int KW);
 int launch_wgrad_small(const float *gz, const float *x, float *dw, void *ws, int B, int C, int H, int W, int KH, int KW,
                        int pt, int pl, float scale, int mask_mode, int mkh, int mkw, hipStream_t s);
 
+// ---- wide layers (scan_wide.hip): C > 64, one small GEMM per anti-diagonal over all images ------------------------
+bool scan_wide_supported(const Geom &g);
+int launch_scan_wide(const float *x, const float *wf, float *z, const Geom &g, int rh, int rw, hipStream_t s);
+
 // ---- general (any C, any K) VALU kernels (scan_general.hip, conv_general.hip) ----------------
 size_t scan_general_lds_bytes(const Geom &g);
 // z = scan(x) with folded taps wf; pixel reflection (rh, rw) applied to both x and z addressing.

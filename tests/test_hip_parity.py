@@ -126,6 +126,8 @@ CASES = [
     (2, 20, 16, 12, 2, 2, "0.05", "TR", 1),
     (1, 9, 20, 8, 3, 3, "0.05", "BL", 0),
     (2, 33, 12, 16, 3, 3, "0.03", "TL", 1),
+    (3, 256, 8, 8, 3, 3, "0.01", "TR", 0),    # wide layers: one GEMM per anti-diagonal over all images (scan_wide.hip)
+    (2, 128, 6, 10, 2, 2, "0.02", "BL", 1),
 ]
 
 

@@ -489,8 +489,10 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
                 }
                 if constexpr (KW > 2) mf(2 * KW + 2, f2h, f2l, 0, 2, true); // first contribution to diagonal d+2
                 chunk_store();
+                if constexpr (KH < 2) {
 #pragma unroll
-                for (int i = 0; i < G; ++i) chunk_dma(i);
+                    for (int i = 0; i < G; ++i) chunk_dma(i);
+                }
                 weave(std::integral_constant<int, 2>{}, N0{}, NGM{}, std::integral_constant<int, 3>{});
             } else {
 #pragma unroll
@@ -538,7 +540,13 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
             if constexpr (KH > 1) {
                 lgkm_wait_n(NRD2); // ... and the dh=1 fragments
                 mf(KW, f1h, f1l, 1, 0);
-                fence();
+                if constexpr (KH > 2) { // (the DMA issue rides here: the last leading group already carries the stores)
+#pragma unroll
+                    for (int i = 0; i < G; ++i) chunk_dma(i);
+                    weave(std::integral_constant<int, 7>{}, N0{}, NGM{}, std::integral_constant<int, 2>{});
+                } else {
+                    fence();
+                }
             }
             IFL_STAMP(3); // critical MFMAs issued
             // ---- trailing: the remaining taps of r_{d-1} with dh < 2 (targets d+1, d+2) and z_{d-1} = L^-1 r_{d-1},

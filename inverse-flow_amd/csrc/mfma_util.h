@@ -7,6 +7,8 @@ namespace ifl {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 
 static constexpr float LO_SCALE = 2048.0f;
 static constexpr float LO_INV = 1.0f / 2048.0f;

@@ -44,8 +44,14 @@
 #include "mfma_util.h"
 #include "scan_general_body.h"
 #include <stdlib.h>
+#include <mutex>
+#include <vector>
 
 namespace ifl {
+
+// mailbox lines per image and wave of a split scan: the upper half fills line d+8 in step d (d <= W+17), the lower half
+// prefetches line d+27 in step d (d <= W+17: the last ones are never written, nor used); the last line is the verdict
+static constexpr int SPLIT_SLOTS = 80;
 
 template <int C, int KH, int KW, int NTILE> struct ScanCfg {
     static constexpr int NW = C / 16;      // 16-channel output groups
@@ -63,7 +69,10 @@ template <int C, int KH, int KW, int NTILE> struct ScanCfg {
     static constexpr int XROWB = 2 * C * 16 + 16; // quads of one row: [parity][channel][4] + pad (x staging and z staging)
     static constexpr int XSB = 16 * NTILE * XROWB;
     static constexpr int OFF_XS = RINGB, OFF_ZQ = OFF_XS + XSB, OFF_DUMP = OFF_ZQ + XSB;
-    static constexpr int LDSB = OFF_DUMP + 4 * 256 + 64 * NWAVES * 8; // dump: where lanes outside the image write their r (branch-free epilogue)
+    static constexpr int OFF_HALO = OFF_DUMP + 4 * 256 + 64 * NWAVES * 8; // dump: where lanes outside the image write their r (branch-free epilogue)
+    static constexpr int HALOB = 1280; // split scan, lower half: landing zone of one wave's halo granules (4 steps in flight)
+    static constexpr int LDSB = OFF_HALO;
+    static constexpr int LDSB_SPLIT = OFF_HALO + NWAVES * HALOB;
     static constexpr int THREADS = 64 * NWAVES;
     static constexpr int ROWS_PER_ITER = 4 * NTILE; // rows that start/finish a quad each step
     static constexpr int G = ROWS_PER_ITER / NWAVES; // ... per wave: G DMAs and G (possibly masked) stores per step
@@ -98,14 +107,16 @@ __device__ unsigned long long *g_stamps = nullptr;
 
 // PAD: the layer has fewer channels than the instantiation (geom.C < C; the weights are padded with the identity by
 // k_foldpack): lanes beyond geom.C move nothing, their x staging is zero.
-template <int C, int KH, int KW, int NTILE, bool PAD>
-__global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__restrict__ xin,
-                                                                    float *__restrict__ zout,
-                                                                    const half8 *__restrict__ apack, int H, int W,
-                                                                    int rh, int rw, int *__restrict__ flags,
-                                                                    const float *__restrict__ wf32, Geom geom,
-                                                                    unsigned *__restrict__ amax)
+// SPLIT: this workgroup owns one row tile (part 0: rows 0..15, part 1: rows 16..) of image b and hands over / receives
+// the rows in between through the mailbox; returns nonzero when the image has to be redone whole (see k_scan_split).
+template <int C, int KH, int KW, int NTILE, bool PAD, bool SPLIT>
+__device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *__restrict__ zout,
+                                         const half8 *__restrict__ apack, const int H, const int W, const int rh,
+                                         const int rw, int *__restrict__ flags, const float *__restrict__ wf32,
+                                         const Geom &geom, unsigned *__restrict__ amax, const SplitState &sp, const int b,
+                                         const int part)
 {
+    static_assert(!SPLIT || NTILE == 1, "a split scan's workgroup owns one row tile");
     using Cfg = ScanCfg<C, KH, KW, NTILE>;
     constexpr int NQ = Cfg::NQ, NS = Cfg::NS, RBB = Cfg::RBB, SLOTB = Cfg::SLOTB, G = Cfg::G;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -117,8 +128,9 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index: scalar
     const int wv = wave; // 16-channel output group of this wave
     const int n = lane & 15, g = lane >> 4;
-    const int b = blockIdx.x;
-    const int ND = H + W - 1;
+    const int hoff = SPLIT ? 16 * part : 0;              // first image row of this workgroup
+    const int Hp = SPLIT ? (part ? H - 16 : 16) : H;     // its rows
+    const int ND = Hp + W - 1;
 
     // ---- zero the r-ring and the zero block (zero padding of the operator) ---------------------------
     {
@@ -152,7 +164,7 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
 #pragma unroll
     for (int T = 0; T < NTILE; ++T) {
         const int h = 16 * T + n;
-        hval[T] = h < H;
+        hval[T] = h < Hp;
 #pragma unroll
         for (int dh = 0; dh < KH; ++dh) {
             const int hs = h - dh + 16; // row block 0 of a slot is the zero block
@@ -183,14 +195,33 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
     const int ro_lds = ro_dma ? (int)ldsbase + Cfg::OFF_XS : (int)ldsbase + Cfg::OFF_ZQ;
     // byte offset of the quad (row hr, columns wq..wq+3) in a stored channel plane = gbase + hr*grow + wq*gcol
     const int grow = rh ? -4 * W : 4 * W, gcol = rw ? -4 : 4;
-    const int gbase = (rh ? (H - 1) * 4 * W : 0) + (rw ? (W - 4) * 4 : 0);
+    const int gbase = (rh ? (H - 1) * 4 * W : 0) + (rw ? (W - 4) * 4 : 0) + hoff * grow;
+    // split scan: the last two rows of the upper half travel to the lower half's workgroup through a mailbox in
+    // global memory, as 8-byte {value, tag} granules (two per 16-byte write-through store; the data is the flag:
+    // MI355X hand-off recipe R2).  Lanes n = 14, 15 own them; a wave's 8 lanes fill one 128-byte line per plane set.
+    const unsigned hl8 = (unsigned)(g * 2 + (n & 1)) * 16;
+    const unsigned long long hmask = 0xC000C000C000C000ull;
+    const unsigned hown = n >= 14 ? ~0u : 0u;
+    unsigned epoch = 0;
+    char *mb = nullptr;
+    int dead = 0; // lower half: the upper half never showed up (bounded spin ran out)
+    if constexpr (SPLIT) {
+        epoch = __builtin_amdgcn_readfirstlane(sp.gen[b] + 1);
+        mb = (char *)sp.mbox + ((size_t)b * SPLIT_SLOTS * Cfg::NW + wave) * 256; // [image][step][wave][hi, lo][8 lanes x 16 B]
+    }
+    constexpr int MBSTEP = Cfg::NW * 256;
+    // the mailbox line of the step at hand (upper half: the one it fills, lower half: the one it prefetches), advanced
+    // once per step; the granule registers keep their tags for the whole sweep
+    unsigned long long hline = 0;
+    uintx4 hv0 = {0u, epoch, 0u, epoch}, hv1 = {0u, epoch, 0u, epoch};
+    const int p_last = W + 14; // last diagonal with a pixel in row 15
 
     float rmax = 0.f;       // max |r| this lane put into the ring: beyond the fp16 range the image is redone in fp32
     float zmax = 0.f;       // max |z| this lane stored (handed to the weight-gradient kernel as its prescale)
     int qprev = 0;          // in-row staging offset (parity, position in the quad) of the previous step's column
     float xscale = 1.f, zscale = 1.f; // scaled retries of an image whose r left the fp16 range
     // kernel arguments used in the loop, held in scalar registers (a reload would wait on the LDS counter)
-    int Hs = H, Ws = W;
+    int Hs = Hp, Ws = W;
     asm volatile("" : "+s"(Hs), "+s"(Ws));
 
     // Rolling accumulators ("push" form): acc[k] collects everything the taps contribute to diagonal d+k; the
@@ -218,6 +249,8 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
 #ifdef IFL_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
     unsigned long long st_mask[4] = {0, 0, 0, 0}, st_cnt[4] = {0, 0, 0, 0};
+    unsigned long long st_slow = 0, st_spins = 0, st_rt[4] = {__builtin_amdgcn_s_memrealtime(), 0, 0, 0};
+    const unsigned long long st_begin = st_last;
 #endif
     __syncthreads();
 
@@ -248,8 +281,38 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
         ro_loff = ro_lds + __mul24(hr, Cfg::XROWB) + ((wq >> 2) & 1) * (C * 16);
         ro_okm = ok ? -1 : 0;
     };
-    auto step = [&](auto mask_c, auto scaled_c, const int d) {
+    // PART: -1 = the whole image in this workgroup; 0 / 1 = upper / lower half of a split scan
+    auto halo_slow = [&](const int d, uintx4 &q0, uintx4 &q1) {
+        // the granules prefetched three steps ago were not there yet: poll them (bounded) with agent-scope loads
+        const unsigned long long *hp = (const unsigned long long *)(mb + (size_t)(d + 24) * MBSTEP + hl8);
+#ifdef IFL_STAMPS
+        st_slow += 1;
+#endif
+        for (int spins = 0;; ++spins) {
+#ifdef IFL_STAMPS
+            st_spins += 1;
+#endif
+            unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            if (n >= 14) {
+                a0 = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a1 = __hip_atomic_load(hp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a2 = __hip_atomic_load(hp + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a3 = __hip_atomic_load(hp + 17, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            q0 = uintx4{(unsigned)a0, (unsigned)(a0 >> 32), (unsigned)a1, (unsigned)(a1 >> 32)};
+            q1 = uintx4{(unsigned)a2, (unsigned)(a2 >> 32), (unsigned)a3, (unsigned)(a3 >> 32)};
+            const bool ok = n < 14 || (q0[1] == epoch && q0[3] == epoch && q1[1] == epoch && q1[3] == epoch);
+            if (__all(ok)) break;
+            if (spins > 20000) { // ~tens of ms: the image is flagged and redone whole by the sweep behind this launch
+                dead = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    };
+    auto step = [&](auto mask_c, auto scaled_c, auto part_c, const int d) {
         constexpr int MASK = decltype(mask_c)::value;
+        constexpr int PART = decltype(part_c)::value;
         constexpr bool SCALED = decltype(scaled_c)::value; // a retry with x scaled down (see the sweep below)
         constexpr int NA = (MASK & 1) + ((MASK >> 1) & 1);
         constexpr int NDH = KH < 2 ? KH : 2;
@@ -272,7 +335,8 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
         // the DMA of step d-3 -- with stores in flight it also asks for a DMA that is two steps old, which has
         // landed long ago -- and never waits for a store of the previous step (a store takes ~2 us to retire).
         // Then the barrier: r of diagonal d-1 and the z staged in step d-1 are complete in LDS.
-        wait_vm_then_barrier<2 * G>();
+        // (split scan: plus the two mailbox operations per step, which follow the DMAs in program order)
+        wait_vm_then_barrier<(PART == 0 ? 2 * G + 6 : PART == 1 ? 2 * G + 4 : 2 * G)>();
         IFL_STAMP(1); // wait + barrier
 
         // in-row staging offset of this step's column w = d - h: the same for all tiles (rows 16 apart)
@@ -285,6 +349,10 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
         floatx4_ sv[G];
         floatx2 xq[NTILE][2];
         half8 Fh[NTILE][2][NQ], Fl[NTILE][2][NQ];
+        // lower half: the halo granules that landed for this step are read behind the dh=2 fragments (two MFMAs of the
+        // first critical group have no request to carry) and used at the end of the step
+        constexpr int NHQ = (PART == 1 && MASK != 0) ? 2 : 0;
+        floatx4_ hq[2];
         constexpr int NREQ = G + (MASK != 0 ? 2 * NA + NDH * PER : 0);
         auto request = [&](int j) {
             int c = 0;
@@ -431,6 +499,43 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
                              : "memory", "scc", "m0");
             }
         };
+        // ---- chunk: mailbox operations of a split scan (always two per step: the wait above counts them) -----------
+        //   upper half: rows 14, 15 of r_d as {value, tag} granules, write-through (zero outside the image: padding)
+        //   lower half: LDS-DMA of the granules of diagonal d+3 (one line per plane set, read once per launch, so a
+        //               stale L1 copy cannot exist; a granule that is not there yet fails its tag check)
+        auto halo_store = [&](const uintx2 hb, const uintx2 lb) {
+            hv0[0] = hb[0];
+            hv0[2] = hb[1];
+            hv1[0] = lb[0];
+            hv1[2] = lb[1];
+            unsigned long long saved;
+            asm volatile("s_mov_b64 %0, exec\n\t"
+                         "s_and_b64 exec, exec, %3\n\t"
+                         "global_store_dwordx4 %4, %1, %5 sc0 sc1\n\t"
+                         "global_store_dwordx4 %4, %2, %5 offset:128 sc0 sc1\n\t"
+                         "s_mov_b64 exec, %0\n\t"
+                         "s_nop 1"
+                         : "=&s"(saved), "+v"(hv0), "+v"(hv1)
+                         : "s"(hmask), "v"(hl8), "s"(hline)
+                         : "memory", "scc");
+        };
+        auto chunk_halo = [&]() {
+            if constexpr (PART == 1) {
+                const unsigned dst = __builtin_amdgcn_readfirstlane(ldsbase + Cfg::OFF_HALO + wave * Cfg::HALOB + ((d + 3) & 3) * 32);
+                unsigned long long saved;
+                asm volatile("s_mov_b32 m0, %1\n\t"
+                             "s_mov_b64 %0, exec\n\t"
+                             "s_and_b64 exec, exec, %2\n\t"
+                             "global_load_lds_dwordx4 %3, %4 sc0 sc1\n\t"
+                             "global_load_lds_dwordx4 %3, %4 offset:128 sc0 sc1\n\t"
+                             "s_mov_b64 exec, %0"
+                             : "=&s"(saved)
+                             : "s"(dst), "s"(hmask), "v"(hl8), "s"(hline)
+                             : "memory", "scc", "m0");
+            } else if constexpr (PART == 0 && MASK == 0) {
+                halo_store(uintx2{0u, 0u}, uintx2{0u, 0u}); // (no diagonal finished: keeps the operation count per step)
+            }
+        };
         // ---- chunk: epilogue of tile T (the chain): r_d = x + acc[0] -> split fp16 -> ring; then the accumulators
         //      rotate: diagonal d+1 becomes the head, a fresh one joins for d+3 -------------------------------
         auto chunk_epilogue = [&](int T) {
@@ -453,6 +558,12 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
             *(half4 *)(rp + 4 * 256) = lo;
             const float m = fmaxf(fmaxf(fabsf(rv[0]), fabsf(rv[1])), fmaxf(fabsf(rv[2]), fabsf(rv[3])));
             rmax = valid ? fmaxf(rmax, m) : rmax;
+            if constexpr (PART == 0) {
+                // (zero outside the image: the operator's padding; an AND, not a select: no branch in this chunk)
+                const uintx2 hb = __builtin_bit_cast(uintx2, hi), lb = __builtin_bit_cast(uintx2, lo);
+                const unsigned vm = valid ? ~0u : 0u;
+                halo_store(uintx2{hb[0] & vm, hb[1] & vm}, uintx2{lb[0] & vm, lb[1] & vm});
+            }
         };
 
         using N0 = std::integral_constant<int, 0>;
@@ -465,6 +576,7 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
             chunk_store();
 #pragma unroll
             for (int i = 0; i < G; ++i) chunk_dma(i);
+            chunk_halo();
             ro_stage(d + 1);
             fence();
         } else {
@@ -492,6 +604,7 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
                 if constexpr (KH < 2) {
 #pragma unroll
                     for (int i = 0; i < G; ++i) chunk_dma(i);
+            chunk_halo();
                 }
                 weave(std::integral_constant<int, 2>{}, N0{}, NGM{}, std::integral_constant<int, 3>{});
             } else {
@@ -501,12 +614,14 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
                 chunk_store();
 #pragma unroll
                 for (int i = 0; i < G; ++i) chunk_dma(i);
+            chunk_halo();
                 fence();
             }
             IFL_STAMP(2); // read issue + leading MFMAs (+ all reads landed, when stamping)
             // ---- critical: taps (0,1) and (1,0) of r_{d-1} -> diagonal d -----------------------------------------
             // The dh=2 fragments of r_{d-1} (next step's leading operands; single-buffered: every MFMA that reads the
             // old ones has been issued) are requested between the first critical MFMAs.
+            const unsigned hqa = ldsbase + Cfg::OFF_HALO + wave * Cfg::HALOB + (d & 3) * 32 + lane * 16;
             auto request2 = [&](int j) {
                 int c = 0;
 #pragma unroll
@@ -532,17 +647,22 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
                             if (MASK & (1 << T)) asm volatile("" : "+a"(ahi[T][0]), "+a"(amid[T][0]));
                         fence();
                         if (k < PER) request2(k);
+                        if constexpr (NHQ) {
+                            if (k == PER || (k == GM - 1 && PER >= GM)) lds_read_f32x4(hq[0], hqa);
+                            if (k == PER + 1 || (k == GM - 1 && PER + 1 >= GM)) lds_read_f32x4(hq[1], hqa + 128);
+                        }
                         fence();
                     }
                 }
                 fence();
             }
             if constexpr (KH > 1) {
-                lgkm_wait_n(NRD2); // ... and the dh=1 fragments
+                lgkm_wait_n(NRD2 + (KH > 2 ? NHQ : 0)); // ... and the dh=1 fragments
                 mf(KW, f1h, f1l, 1, 0);
                 if constexpr (KH > 2) { // (the DMA issue rides here: the last leading group already carries the stores)
 #pragma unroll
                     for (int i = 0; i < G; ++i) chunk_dma(i);
+            chunk_halo();
                     weave(std::integral_constant<int, 7>{}, N0{}, NGM{}, std::integral_constant<int, 2>{});
                 } else {
                     fence();
@@ -636,7 +756,30 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
             IFL_STAMP(5); // trailing MFMAs issued
         }
 
+        if constexpr (NHQ) {
+            // lower half: rows 14, 15 of the upper half's diagonal d+16 join this step's r in the ring (row block 0)
+            if (!dead && d + 16 <= p_last) {
+                if constexpr (KH <= 2) { // (no dh=2 group to ride on)
+                    const unsigned hqa = ldsbase + Cfg::OFF_HALO + wave * Cfg::HALOB + (d & 3) * 32 + lane * 16;
+                    lds_read_f32x4(hq[0], hqa);
+                    lds_read_f32x4(hq[1], hqa + 128);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hq[0]), "+v"(hq[1])::"memory");
+                uintx4 q0 = __builtin_bit_cast(uintx4, hq[0]), q1 = __builtin_bit_cast(uintx4, hq[1]);
+                const unsigned miss = ((q0[1] ^ epoch) | (q0[3] ^ epoch) | (q1[1] ^ epoch) | (q1[3] ^ epoch)) & hown;
+                if (__any(miss != 0)) halo_slow(d, q0, q1);
+                unsigned char *hp = ring + dstoff + wadr[0] - RBB; // (lanes n < 14 write rows nobody reads)
+                *(unsigned *)hp = q0[0];
+                *(unsigned *)(hp + 4) = q0[2];
+                *(unsigned *)(hp + 4 * 256) = q1[0];
+                *(unsigned *)(hp + 4 * 256 + 4) = q1[2];
+            }
+        }
+        if constexpr (PART >= 0) hline += MBSTEP;
         qprev = qcur;
+#ifdef IFL_STAMPS
+        if (PART == 0 && d == 18) st_rt[3] = __builtin_amdgcn_s_memrealtime();
+#endif
         IFL_STAMP(6); // bookkeeping
 #ifdef IFL_STAMPS
         st_mask[MASK] += st_last - st_t0;
@@ -648,35 +791,68 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
     // the step after its last one (the z product of the last diagonal): the sets of active tiles come in the
     // order {}, {0}, {0,1}, {1}, {} -- one loop per set, so that no control flow merges inside a step.  The last
     // step stores the quads staged by the one before.
-    auto sweep = [&](auto scaled_c) {
+    auto sweep = [&](auto scaled_c, auto part_c) {
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
         const int last0 = (15 + W - 1 < ND - 1 ? 15 + W - 1 : ND - 1) + 1; // last step of tile 0
-        int d = -3;
+        // (the lower half of a split scan starts two steps early: its first halo granules are due at step -2 and
+        // are requested three steps ahead)
+        int d = decltype(part_c)::value == 1 ? -5 : -3;
+        if constexpr (decltype(part_c)::value == 0) hline = (unsigned long long)(mb + (size_t)(d + 8) * MBSTEP);
+        if constexpr (decltype(part_c)::value == 1) hline = (unsigned long long)(mb + (size_t)(d + 27) * MBSTEP);
         ro_stage(d);
-        step(I0{}, scaled_c, d++);
+        for (; d < -2; ++d) step(I0{}, scaled_c, part_c, d);
         if constexpr (NTILE == 2) {
             using I2 = std::integral_constant<int, 2>;
             using I3 = std::integral_constant<int, 3>;
-            for (; d < 14; ++d) step(I1{}, scaled_c, d);
-            for (; d <= last0; ++d) step(I3{}, scaled_c, d);
-            for (; d <= ND; ++d) step(I2{}, scaled_c, d);
+            for (; d < 14; ++d) step(I1{}, scaled_c, part_c, d);
+            for (; d <= last0; ++d) step(I3{}, scaled_c, part_c, d);
+            for (; d <= ND; ++d) step(I2{}, scaled_c, part_c, d);
         } else {
-            for (; d <= last0; ++d) step(I1{}, scaled_c, d);
+            for (; d <= last0; ++d) step(I1{}, scaled_c, part_c, d);
         }
-        for (; d <= ND + 2; ++d) step(I0{}, scaled_c, d);
+        for (; d <= ND + 2; ++d) step(I0{}, scaled_c, part_c, d);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every DMA and store of the sweep has retired
     };
-    sweep(std::false_type{});
+    using PWhole = std::integral_constant<int, -1>;
+    if constexpr (SPLIT) {
+        if (part == 0) {
+#ifdef IFL_STAMPS
+            st_rt[1] = __builtin_amdgcn_s_memrealtime();
+#endif
+            sweep(std::false_type{}, std::integral_constant<int, 0>{});
+        } else {
+            // Gate: start once the upper half's diagonal 14 + GATE is visible.  Every prefetch (three steps ahead) then
+            // finds its granules; without the gate the first ones are requested before they exist and each costs a
+            // round of polling (measured: 7 episodes, 30k cycles).
+            constexpr int GATE = 3;
+            uintx4 q0, q1;
+            halo_slow(GATE - 2, q0, q1);
+#ifdef IFL_STAMPS
+            st_rt[1] = __builtin_amdgcn_s_memrealtime();
+#endif
+            sweep(std::false_type{}, std::integral_constant<int, 1>{});
+        }
+    } else {
+        sweep(std::false_type{}, PWhole{});
+    }
 
 #ifdef IFL_STAMPS
+    // (the redo sweep behind a split launch never gets here for image 0 unless it was flagged)
     if (g_stamps && b == 0 && lane == 0)
-        for (int k = 0; k < 8; ++k) g_stamps[wave * 8 + k] = st_acc[k];
-    if (g_stamps && b == 0 && lane == 0 && wave == 0)
+        for (int k = 0; k < 8; ++k) g_stamps[part * 80 + wave * 8 + k] = st_acc[k];
+    if (g_stamps && b == 0 && lane == 0 && wave == 0) {
         for (int k = 0; k < 4; ++k) {
-            g_stamps[64 + k] = st_mask[k];
-            g_stamps[68 + k] = st_cnt[k];
+            g_stamps[part * 80 + 64 + k] = st_mask[k];
+            g_stamps[part * 80 + 68 + k] = st_cnt[k];
         }
+        st_rt[2] = __builtin_amdgcn_s_memrealtime();
+        for (int k = 0; k < 4; ++k) g_stamps[part * 80 + 72 + k] = st_rt[k];
+        g_stamps[part * 80 + 76] = st_slow;
+        g_stamps[part * 80 + 77] = st_spins;
+        g_stamps[part * 80 + 78] = st_begin;
+        g_stamps[part * 80 + 79] = __builtin_amdgcn_s_memtime();
+    }
 #endif
     // Split fp16 cannot hold |r| >= 65504, and a badly conditioned operator grows r along the sweep.  Such an image
     // is swept once more by the same workgroup with x scaled down by 2^-12 and z scaled back up: the recurrence is
@@ -686,6 +862,42 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
     // is not finite, the exact fp32 body takes over (general scan body, right-fold form, fp32 copy of the same folded
     // weights): slow, but never a silent Inf/NaN where the exact solver is finite.  flags[] records what happened
     // (diagnostics only: 0, 1 = rescaled, +4 = fp32).
+    if constexpr (SPLIT) {
+        // A half that left the fp16 range (or lost its partner) makes the image void: the lower half's workgroup then
+        // redoes it whole (scaled retry, fp32 body).  The upper half tells it through a verdict granule; if its own
+        // rows are void it first writes its L2's dirty lines back (agent-scope release), so that they cannot land on
+        // top of the redone rows later (the two workgroups may sit on XCDs with separate L2s).
+        int bad = __syncthreads_or((rmax < 6.0e4f ? 0 : 1) | dead); // (every wave is behind its vmcnt(0): sweep end)
+        if (amax) {
+            for (int o = 32; o > 0; o >>= 1) zmax = fmaxf(zmax, __shfl_down(zmax, o, 64));
+            if (lane == 0) atomicMax(amax, __float_as_uint(zmax));
+        }
+        unsigned long long *verdict = (unsigned long long *)((char *)sp.mbox + (size_t)b * SPLIT_SLOTS * MBSTEP + (SPLIT_SLOTS - 1) * MBSTEP);
+        if (part == 0) {
+            if (tid == 0) {
+                if (bad) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __hip_atomic_store(verdict, ((unsigned long long)epoch << 32) | (unsigned)(bad ? 2 : 1), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            // (the upper half finished some twenty steps ago: one poll in practice; bounded all the same)
+            unsigned pv = 0;
+            for (int spins = 0; spins < 20000; ++spins) {
+                const unsigned long long v = __hip_atomic_load(verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(v >> 32) == epoch) {
+                    pv = (unsigned)v;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            bad |= pv != 1; // (no verdict in time counts as void)
+            bad = __syncthreads_or(bad);
+        }
+        return bad;
+    } else {
     int redo = __syncthreads_or(rmax < 6.0e4f ? 0 : 1);
     int attempts = 0;
     while (redo && attempts < 1) {
@@ -715,7 +927,7 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
         zmax = 0.f;
         qprev = 0;
         __syncthreads();
-        sweep(std::true_type{});
+        sweep(std::true_type{}, PWhole{});
         redo = __syncthreads_or(rmax < 6.0e4f ? 0 : 1);
     }
     if (tid == 0) flags[b] = attempts + (redo ? 4 : 0); // every workgroup owns its word: no clearing pass needed
@@ -731,6 +943,48 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
     if (amax) {
         for (int o = 32; o > 0; o >>= 1) zmax = fmaxf(zmax, __shfl_down(zmax, o, 64));
         if (lane == 0) atomicMax(amax, __float_as_uint(zmax)); // one atomic per wave; max is order-independent
+    }
+    } // !SPLIT
+    return 0;
+}
+
+template <int C, int KH, int KW, int NTILE, bool PAD>
+__global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__restrict__ xin, float *__restrict__ zout,
+                                                             const half8 *__restrict__ apack, int H, int W, int rh, int rw,
+                                                             int *__restrict__ flags, const float *__restrict__ wf32,
+                                                             Geom geom, unsigned *__restrict__ amax)
+{
+    const SplitState none{nullptr, nullptr};
+    scan_body<C, KH, KW, NTILE, PAD, false>(xin, zout, apack, H, W, rh, rw, flags, wf32, geom, amax, none, (int)blockIdx.x, 0);
+}
+
+// Split scan (16 < H <= 32, at most half as many images as compute units): two workgroups per image, one row tile
+// each.  The both-tiles steps of the whole-image kernel (3260 cycles) become one-tile steps (~2100) on twice the
+// compute units; the lower half runs 14 + 4.5 diagonals behind the upper one (dependency + hand-off).  Workgroups
+// i and i+8 pair up (the same XCD under the observed round-robin placement: speed only); the upper half has the
+// lower index and never waits for anybody, so the pair cannot deadlock whatever the dispatch order does; every
+// spin of the lower half is bounded, and an image whose hand-off failed is simply redone whole.
+template <int C, int KH, int KW, bool PAD>
+__global__ __launch_bounds__(64 * (C / 16)) void k_scan_split(const float *__restrict__ xin, float *__restrict__ zout,
+                                                              const half8 *__restrict__ apack, int H, int W, int rh, int rw,
+                                                              int *__restrict__ flags, const float *__restrict__ wf32,
+                                                              Geom geom, unsigned *__restrict__ amax, SplitState sp)
+{
+    const int b = (int)((blockIdx.x >> 4) * 8 + (blockIdx.x & 7));
+    const int part = (blockIdx.x >> 3) & 1;
+    if (b >= geom.B) return;
+    const int bad = scan_body<C, KH, KW, 1, PAD, true>(xin, zout, apack, H, W, rh, rw, flags, wf32, geom, amax, sp, b, part);
+    if (part == 0) return;
+    if (bad) {
+        __syncthreads();
+        scan_body<C, KH, KW, 2, PAD, false>(xin, zout, apack, H, W, rh, rw, flags, wf32, geom, amax, sp, b, 0);
+    } else if (threadIdx.x == 0) {
+        flags[b] = 0;
+    }
+    // the next launch uses another tag (both halves have read this one long ago; gen + 1 is never 0)
+    if (threadIdx.x == 0) {
+        const unsigned gnext = sp.gen[b] + 1;
+        sp.gen[b] = gnext == 0xFFFFFFFFu ? 0u : gnext;
     }
 }
 
@@ -936,7 +1190,7 @@ template <int C> __global__ __launch_bounds__(256) void k_foldpack(FoldJobs jobs
     IFL_FSTAMP(); // 3: product + pack
 #ifdef IFL_STAMPS
     if (g_stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0)
-        for (int k = 0; k < 4; ++k) g_stamps[72 + k] = ft[k];
+        for (int k = 0; k < 4; ++k) g_stamps[160 + k] = ft[k];
 #endif
 }
 
@@ -980,6 +1234,56 @@ int launch_foldpack_mfma(const float *w, void *out0, float *wf0, void *out1, flo
     return launch_foldpack_jobs(jobs, 1, ndir, s);
 }
 
+// ---- split-scan state: one block per (device, stream), allocated and zeroed on first use, never freed -----------
+// Layout: [generation per image, 128 words] [mailbox: 128 images x 80 steps x 4 waves x 256 B; the last step = verdict].
+// Tags are per-image launch generations, so the mailbox needs no cleaning between launches; generations advance on
+// the device (the lower half's last act), which keeps the scheme valid under graph replay.
+namespace {
+constexpr int SPLIT_MAX_IMAGES = 128;
+constexpr size_t SPLIT_MBOX_OFF = SPLIT_MAX_IMAGES * sizeof(unsigned);
+constexpr size_t SPLIT_BYTES = SPLIT_MBOX_OFF + (size_t)SPLIT_MAX_IMAGES * SPLIT_SLOTS * 4 * 256;
+struct SplitBlock {
+    int dev;
+    hipStream_t stream;
+    char *ptr;
+};
+std::mutex g_split_mu;
+std::vector<SplitBlock> g_split_blocks;
+} // namespace
+
+// the block of this device and stream, or nullptr when it cannot be had right now (stream capture in progress)
+static char *split_state(hipStream_t s)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(g_split_mu);
+    for (const SplitBlock &e : g_split_blocks)
+        if (e.dev == dev && e.stream == s) return e.ptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+    char *ptr = nullptr;
+    if (hipMalloc((void **)&ptr, SPLIT_BYTES) != hipSuccess) return nullptr;
+    if (hipMemset(ptr, 0, SPLIT_BYTES) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipFree(ptr);
+        return nullptr;
+    }
+    g_split_blocks.push_back(SplitBlock{dev, s, ptr});
+    return ptr;
+}
+
+static int device_cus()
+{
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!cus[dev]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        cus[dev] = v;
+    }
+    return cus[dev];
+}
+
 template <int C, int KH, int KW, int NTILE, bool PAD>
 static int launch_one(const float *x, float *z, const void *apack, const Geom &g, int rh, int rw, int *flags,
                       const float *wf32, unsigned *amax, hipStream_t s)
@@ -988,8 +1292,8 @@ static int launch_one(const float *x, float *z, const void *apack, const Geom &g
     static_assert(Cfg::LDSB <= 160 * 1024, "ring + x staging must fit the CU's LDS");
     static bool attr_done = false; // idempotent attribute, benign race
     if (!attr_done) {
-        IFL_HIP(hipFuncSetAttribute((const void *)k_scan_mfma<C, KH, KW, NTILE, PAD>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    Cfg::LDSB));
+        IFL_HIP(hipFuncSetAttribute((const void *)k_scan_mfma<C, KH, KW, NTILE, PAD>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDSB));
         attr_done = true;
     }
     if (scan_general_lds_bytes(g) > (size_t)Cfg::LDSB)
@@ -1000,6 +1304,26 @@ static int launch_one(const float *x, float *z, const void *apack, const Geom &g
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &ptr, sizeof(ptr));
     }
 #endif
+    if constexpr (NTILE == 2) {
+        // Split the image over two workgroups when that still leaves one compute unit per workgroup (k_scan_split).
+        // IFL_NO_SPLIT=1 keeps the whole-image mapping.
+        static const bool no_split = getenv("IFL_NO_SPLIT") && atoi(getenv("IFL_NO_SPLIT"));
+        char *st = nullptr;
+        if (!no_split && g.B <= SPLIT_MAX_IMAGES && 2 * g.B <= device_cus() && (st = split_state(s))) {
+            static bool attr_s = false;
+            if (!attr_s) {
+                IFL_HIP(hipFuncSetAttribute((const void *)k_scan_split<C, KH, KW, PAD>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDSB));
+                attr_s = true;
+            }
+            static_assert(ScanCfg<C, KH, KW, 1>::LDSB_SPLIT <= Cfg::LDSB, "the redo of a split scan runs in the same allocation");
+            const SplitState sp{(unsigned long long *)(st + SPLIT_MBOX_OFF), (unsigned *)st};
+            hipLaunchKernelGGL((k_scan_split<C, KH, KW, PAD>), dim3(16 * ((g.B + 7) / 8)), dim3(Cfg::THREADS), Cfg::LDSB, s,
+                               x, z, (const half8 *)apack, g.H, g.W, rh, rw, flags, wf32, g, amax, sp);
+            IFL_HIP(hipGetLastError());
+            return IFL_OK;
+        }
+    }
     hipLaunchKernelGGL((k_scan_mfma<C, KH, KW, NTILE, PAD>), dim3(g.B), dim3(Cfg::THREADS), Cfg::LDSB, s, x, z,
                        (const half8 *)apack, g.H, g.W, rh, rw, flags, wf32, g, amax);
     IFL_HIP(hipGetLastError());

@@ -143,17 +143,29 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
 
     // ---- folded weights -> registers (A fragments, hi and lo) -----------------------------------
     half8 A[NS][NQ][2];
+    {
+        // all loads first, then the pins: a pin right behind its load makes every load wait for its own data
+        // (36 dependent L2 round trips at C = 64, 3x3)
+        half8 Aload[NS][NQ][2];
 #pragma unroll
-    for (int s = 0; s < NS; ++s)
+        for (int s = 0; s < NS; ++s)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
+            for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int hl = 0; hl < 2; ++hl) {
-                A[s][q][hl] = apack[((((size_t)wv * NS + s) * NQ + q) * 2 + hl) * 64 + lane];
-                // pin the fragment in the accumulator half of the register file (MFMA reads A from AGPRs
-                // directly); without this hipcc re-loads the weights from memory inside the scan loop
-                asm volatile("" : "+a"(A[s][q][hl]));
-            }
+                for (int hl = 0; hl < 2; ++hl)
+                    Aload[s][q][hl] = apack[((((size_t)wv * NS + s) * NQ + q) * 2 + hl) * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) {
+                    A[s][q][hl] = Aload[s][q][hl];
+                    // pin the fragment in the accumulator half of the register file (MFMA reads A from AGPRs
+                    // directly); without this hipcc re-loads the weights from memory inside the scan loop
+                    asm volatile("" : "+a"(A[s][q][hl]));
+                }
+    }
 
     // ---- per-lane constants: lane (n, g) owns pixel rows h = 16T+n and channels c0..c0+3 (C/D layout) ----
     const int c0 = 16 * wv + 4 * g;

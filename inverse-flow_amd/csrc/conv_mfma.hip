@@ -99,15 +99,27 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_conv_mfma(const float *__rest
 #endif
     // ---- weights -> registers (pinned in the accumulator half of the register file, see scan_mfma.hip) ------------
     half8 A[NT][NQ][2];
+    {
+        // all loads first, then the pins (a pin right behind its load makes every load wait for its own data)
+        half8 Aload[NT][NQ][2];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
+            for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int hl = 0; hl < 2; ++hl) {
-                A[t][q][hl] = apack[((((size_t)wv * NT + t) * NQ + q) * 2 + hl) * 64 + lane];
-                asm volatile("" : "+a"(A[t][q][hl]));
-            }
+                for (int hl = 0; hl < 2; ++hl)
+                    Aload[t][q][hl] = apack[((((size_t)wv * NT + t) * NQ + q) * 2 + hl) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) {
+                    A[t][q][hl] = Aload[t][q][hl];
+                    asm volatile("" : "+a"(A[t][q][hl]));
+                }
+    }
+
 
     // ---- staging.  Interior: item = (k-group of 8 channels, staged row, quad of 4 columns): eight 16-byte loads
     //      (one per channel, lanes along w: fully coalesced) into registers -- issued for the NEXT band before the

@@ -203,7 +203,6 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
     const int ro_hb = 4 * (wave + Cfg::NWAVES * ro_i); // first row of the operation's row class
     const int ro_ko = ro_dma ? 3 : -5;                 // first column of the quad = d + ko - h (rows h = d-1 mod 4 are due)
     const unsigned long long ro_base = ro_dma ? (unsigned long long)xg : (unsigned long long)zg;
-    const unsigned long long ro_bad = ro_dma ? (unsigned long long)xg : (unsigned long long)zg;   // no quad due
     const int ro_lds = ro_dma ? (int)ldsbase + Cfg::OFF_XS : (int)ldsbase + Cfg::OFF_ZQ;
     // byte offset of the quad (row hr, columns wq..wq+3) in a stored channel plane = gbase + hr*grow + wq*gcol
     const int grow = rh ? -4 * W : 4 * W, gcol = rw ? -4 : 4;
@@ -226,7 +225,7 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
     // once per step; the granule registers keep their tags for the whole sweep
     unsigned long long hline = 0;
     uintx4 hv0 = {0u, epoch, 0u, epoch}, hv1 = {0u, epoch, 0u, epoch};
-    const int p_last = W + 14; // last diagonal with a pixel in row 15
+    int p_last = W + 14; // last diagonal with a pixel in row 15 (lower half: set far below once the hand-off is dead)
 
     float rmax = 0.f;       // max |r| this lane put into the ring: beyond the fp16 range the image is redone in fp32
     float zmax = 0.f;       // max |z| this lane stored (handed to the weight-gradient kernel as its prescale)
@@ -287,7 +286,8 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
         const int wq = d + ro_ko - hr;
         const bool ok = hr < Hs && (unsigned)wq < (unsigned)Ws;
         const unsigned goff = (unsigned)(gbase + __mul24(hr, grow) + __mul24(wq, gcol));
-        const unsigned long long a = ok ? ro_base + goff : ro_bad;
+        // (no quad due: the buffer's first quad -- a 32-bit select, then one add: the 64-bit select became a branch)
+        const unsigned long long a = ro_base + (ok ? goff : 0u);
         ro_alo = (int)(unsigned)a;
         ro_ahi = (int)(unsigned)(a >> 32);
         ro_loff = ro_lds + __mul24(hr, Cfg::XROWB) + ((wq >> 2) & 1) * (C * 16);
@@ -317,6 +317,7 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
             if (__all(ok)) break;
             if (spins > 20000) { // ~tens of ms: the image is flagged and redone whole by the sweep behind this launch
                 dead = 1;
+                p_last = -1000;
                 break;
             }
             __builtin_amdgcn_s_sleep(2);
@@ -770,7 +771,7 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
 
         if constexpr (NHQ) {
             // lower half: rows 14, 15 of the upper half's diagonal d+16 join this step's r in the ring (row block 0)
-            if (!dead && d + 16 <= p_last) {
+            if (d + 16 <= p_last) {
                 if constexpr (KH <= 2) { // (no dh=2 group to ride on)
                     const unsigned hqa = ldsbase + Cfg::OFF_HALO + wave * Cfg::HALOB + (d & 3) * 32 + lane * 16;
                     lds_read_f32x4(hq[0], hqa);
@@ -778,7 +779,19 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hq[0]), "+v"(hq[1])::"memory");
                 uintx4 q0 = __builtin_bit_cast(uintx4, hq[0]), q1 = __builtin_bit_cast(uintx4, hq[1]);
-                const unsigned miss = ((q0[1] ^ epoch) | (q0[3] ^ epoch) | (q1[1] ^ epoch) | (q1[3] ^ epoch)) & hown;
+                // all four tags against this launch's, on the vector unit (the compiler turns the plain expression into
+                // four compares and a chain of scalar ORs: twice the issue time)
+                unsigned miss, mt;
+                asm("v_xor_b32 %0, %2, %6\n\t"
+                    "v_xor_b32 %1, %3, %6\n\t"
+                    "v_or_b32 %0, %0, %1\n\t"
+                    "v_xor_b32 %1, %4, %6\n\t"
+                    "v_or_b32 %0, %0, %1\n\t"
+                    "v_xor_b32 %1, %5, %6\n\t"
+                    "v_or_b32 %0, %0, %1\n\t"
+                    "v_and_b32 %0, %0, %7"
+                    : "=&v"(miss), "=&v"(mt)
+                    : "v"(q0[1]), "v"(q0[3]), "v"(q1[1]), "v"(q1[3]), "s"(epoch), "v"(hown));
                 if (__any(miss != 0)) halo_slow(d, q0, q1);
                 unsigned char *hp = ring + dstoff + wadr[0] - RBB; // (lanes n < 14 write rows nobody reads)
                 *(unsigned *)hp = q0[0];

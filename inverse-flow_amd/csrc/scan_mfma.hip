@@ -1332,7 +1332,8 @@ static int launch_one(const float *x, float *z, const void *apack, const Geom &g
     if constexpr (NTILE == 2) {
         // Split the image over two workgroups when that still leaves one compute unit per workgroup (k_scan_split).
         // IFL_NO_SPLIT=1 keeps the whole-image mapping.
-        static const bool no_split = getenv("IFL_NO_SPLIT") && atoi(getenv("IFL_NO_SPLIT"));
+        const char *ns = getenv("IFL_NO_SPLIT"); // (read per launch: the tests flip it)
+        const bool no_split = ns && atoi(ns);
         char *st = nullptr;
         if (!no_split && g.B <= SPLIT_MAX_IMAGES && 2 * g.B <= device_cus() && (st = split_state(s))) {
             static bool attr_s = false;

@@ -324,3 +324,64 @@ def test_empty_batch_and_errors(H):
     with pytest.raises(RuntimeError, match="LDS"):
         H.inverse(torch.zeros(1, 256, 64, 64, device="cuda"), torch.zeros(256, 256, 3, 3, device="cuda"),
                   flags=H.FLAG_NO_MFMA)
+
+
+def _no_split(on):
+    """the library reads IFL_NO_SPLIT at every scan launch (scan_mfma.hip, launch_one)"""
+    if on:
+        os.environ["IFL_NO_SPLIT"] = "1"
+    else:
+        os.environ.pop("IFL_NO_SPLIT", None)
+
+
+@pytest.mark.parametrize("shape", [(128, 64, 32, 32, 3), (128, 32, 32, 16, 3), (40, 64, 24, 32, 2), (13, 48, 32, 32, 3)],
+                         ids=lambda s: "B%d_C%d_%dx%d_K%d" % s)
+def test_split_scan_equals_whole_image_scan(H, shape):
+    """Two workgroups per image (k_scan_split: mailbox hand-off of rows 14, 15) against one workgroup per image, at the
+    bench's full size and on ragged ones (H not a multiple of 16, padded channels, a batch that is not a multiple of 8).
+    The arithmetic per tile is the same instruction sequence on the same operands, so the results are bit-identical --
+    on every one of many back-to-back launches (tags are per-image launch generations: a stale granule of an earlier
+    launch must never be taken for a fresh one), for all four orders, forward and adjoint."""
+    B, C, Hh, Ww, K = shape
+    gen = torch.Generator().manual_seed(5)
+    w = torch.nn.init.dirac_(torch.empty(C, C, K, K)) + 0.02 * torch.randn(C, C, K, K, generator=gen)
+    w[:, -1, -1, -1] = 1.0
+    w = w.cuda()
+    x = torch.randn(B, C, Hh, Ww, generator=gen).cuda()
+    for order in ("TL", "TR", "BL", "BR"):
+        _no_split(True)
+        try:
+            z_ref = H.inverse(x, w, order)
+            dx_ref, dw_ref, _ = H.backward(x, z_ref, w, order)
+        finally:
+            _no_split(False)
+        for it in range(12 if order == "TL" else 2):
+            z = H.inverse(x, w, order)
+            assert torch.equal(z, z_ref), (order, it)
+        dx, dw, _ = H.backward(x, z_ref, w, order)
+        assert torch.equal(dx, dx_ref) and torch.equal(dw, dw_ref)
+    torch.cuda.synchronize()
+
+
+def test_split_scan_redoes_void_images_whole(H, oracle):
+    """Images whose r leaves the fp16 range in the LOWER half only, in both halves, and in neither, mixed in one batch:
+    the lower half's workgroup redoes a void image whole (scaled retry / fp32 body) and the flags say which."""
+    rng = np.random.default_rng(33)
+    B, C, Hh, Ww, K = 6, 64, 32, 32, 3
+    w = np.zeros((C, C, K, K)); w[np.arange(C), np.arange(C), 1, 1] = 1.0
+    w = (w + 0.03 * rng.standard_normal((C, C, K, K))).astype(np.float32)  # grows r to ~1e7 over a full image
+    x = rng.standard_normal((B, C, Hh, Ww)).astype(np.float32)
+    x[1] *= 1e-4       # stays inside fp16 everywhere
+    x[2, :, :12] = 0   # growth starts late: only the lower half overflows
+    x[4] *= 1e-5
+    z_o = oracle.inverse(x.astype(np.float64), w.astype(np.float64), 0, "TL", nthreads=8)
+    z = H.inverse(dev(x), dev(w))
+    for b in range(B):
+        assert rel_err(host(z)[b], z_o[b]) < TOL, b
+    _no_split(True)
+    try:
+        z_w = H.inverse(dev(x), dev(w))
+    finally:
+        _no_split(False)
+    for b in range(B):
+        assert rel_err(host(z_w)[b], z_o[b]) < TOL, b

@@ -125,6 +125,9 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
     unsigned char *zq = lds + Cfg::OFF_ZQ;
 
     const int tid = threadIdx.x;
+#ifdef IFL_STAMPS
+    const unsigned long long st_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index: scalar
     const int wv = wave; // 16-channel output group of this wave
     const int n = lane & 15, g = lane >> 4;
@@ -804,6 +807,7 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
         qprev = qcur;
 #ifdef IFL_STAMPS
         if (PART == 0 && d == 18) st_rt[3] = __builtin_amdgcn_s_memrealtime();
+        if (PART == 1 && d == -5) st_rt[3] = st_entry;
 #endif
         IFL_STAMP(6); // bookkeeping
 #ifdef IFL_STAMPS

@@ -25,7 +25,7 @@ for part in range(2):
   print("== part", part, "(whole image)" if int(both[80:].abs().sum()) == 0 else "(split scan)")
   print("   begin", int(full[78]), "end", int(full[79]), "span", int(full[79] - full[78]), "memtime ticks; halo slow paths", int(full[76]), "polls", int(full[77]))
   rt = [int(v) for v in full[72:76]]
-  print("   realtime (10 ns ticks, relative to part 0's start): begin", rt[0] - int(both[72]), "sweep start", rt[1] - int(both[72]), "end", rt[2] - int(both[72]), "step 18 done", rt[3] - int(both[72]) if rt[3] else None)
+  print("   realtime (10 ns ticks, relative to part 0's start): begin", rt[0] - int(both[72]), "sweep start", rt[1] - int(both[72]), "end", rt[2] - int(both[72]), "upper half: step 18 done / lower half: kernel entry", rt[3] - int(both[72]) if rt[3] else None)
   t = full[:64].view(8, 8)
   names = ["dma", "wait+bar", "reads+lead", "crit", "epilogue", "trail", "stores", "loop"]
   for wv in range(8):

@@ -159,6 +159,39 @@ int ifl_conv2d_igrad_f32(const float *gz, const float *w, float *dx, int B, int 
 /* scratch for the three calls above (ifl_conv2d_f32 also runs without: ws = NULL selects the direct kernel) */
 size_t ifl_conv2d_workspace_bytes(int B, int Ci, int Co, int H, int W, int KH, int KW, int ph, int pw);
 
+/* ---- Glow-step neighbours of the layer: one pass over an NCHW activation each ------------
+ * Replaces the eager torch elementwise graphs of inf/layers/actnorm.py, squeeze.py and coupling.py (the
+ * conditioner network of the coupling stays a library convolution stack: it is handed in as h).
+ */
+size_t ifl_glow_workspace_bytes(int B, int C); /* scratch of the calls below that take ws */
+
+/* ActNorm (inf/layers/actnorm.py:18-69).  forward: y = (x - t_c) exp(-ls_c), logdet[b] = -H W sum_c ls_c
+ * (logdet may be NULL); reverse != 0: y = x exp(ls_c) + t_c (logdet untouched).  y may alias x. */
+int ifl_actnorm_f32(const float *x, const float *translation, const float *log_scale, float *y, float *logdet, int B,
+                    int C, int H, int W, int reverse, ifl_stream_t stream);
+/* backward of the forward direction: gx = gy exp(-ls); g_translation_c = -exp(-ls_c) sum gy;
+ * g_log_scale_c = -sum gy y - H W sum_b g_logdet[b]  (g_logdet, g_translation, g_log_scale may be NULL). */
+int ifl_actnorm_backward_f32(const float *gy, const float *g_logdet, const float *x, const float *translation,
+                             const float *log_scale, float *gx, float *g_translation, float *g_log_scale, int B, int C,
+                             int H, int W, void *ws, size_t ws_bytes, ifl_stream_t stream);
+/* data-dependent initialisation (actnorm.py:21-28): mean_c, log(std_c + 1e-8) over (B, H, W), std unbiased. */
+int ifl_actnorm_stats_f32(const float *x, float *mean, float *log_std, int B, int C, int H, int W, void *ws,
+                          size_t ws_bytes, ifl_stream_t stream);
+
+/* Squeeze (inf/layers/squeeze.py:5-25).  (C, H, W) is the LARGE layout.  reverse = 0: space_to_depth,
+ * x (B,C,H,W) -> y (B,4C,H/2,W/2); reverse != 0: depth_to_space, x (B,4C,H/2,W/2) -> y (B,C,H,W). */
+int ifl_squeeze_f32(const float *x, float *y, int B, int C, int H, int W, int reverse, ifl_stream_t stream);
+
+/* Coupling, affine part (inf/layers/coupling.py:66-98).  h = net(x1) (B,C,H,W): h_s = h[:,0::2], t = h[:,1::2],
+ * log_s = 2 tanh(h_s/2).  forward: y = cat(x1, x2 exp(log_s) + t), logdet[b] = sum log_s (may be NULL);
+ * reverse != 0: y = cat(x1, (x2 - t) exp(-log_s)).  y may alias x. */
+int ifl_coupling_f32(const float *x, const float *h, float *y, float *logdet, int B, int C, int H, int W, int reverse,
+                     void *ws, size_t ws_bytes, ifl_stream_t stream);
+/* backward of the forward direction: gx = cat(gy1, gy2 exp(log_s)) (the path through the net is the caller's),
+ * gh[:,1::2] = gy2, gh[:,0::2] = (gy2 x2 exp(log_s) + g_logdet[b]) (1 - tanh^2(h_s/2)).  g_logdet may be NULL. */
+int ifl_coupling_backward_f32(const float *gy, const float *g_logdet, const float *x, const float *h, float *gx, float *gh,
+                              int B, int C, int H, int W, ifl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,416 @@
+// The Glow-step neighbours of the inverse-conv layer: ActNorm, Squeeze / UnSqueeze and the
+// affine part of Coupling.  All of them are one pass over an NCHW activation: HBM-bound elementwise work with, at
+// most, a per-channel or per-image reduction -- 16 bytes per lane, whole (image, channel) planes per workgroup,
+// fixed-order two-stage reductions (deterministic: no atomics on floats).
+//
+//   ActNorm   inf/layers/actnorm.py:18-69      y = (x - t_c) exp(-ls_c),  logdet = -H W sum_c ls_c
+//   Squeeze   inf/layers/squeeze.py:5-25       space_to_depth / depth_to_space (a permutation)
+//   Coupling  inf/layers/coupling.py:66-98     z2 = x2 exp(log_s) + t,  log_s = 2 tanh(h_s / 2),  h = net(x1)
+//             (the conditioner net is three library convolutions and stays where it is: only what touches the
+//              activation elementwise is here)
+#include "ifl_common.h"
+
+namespace ifl {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+static constexpr int GS_T = 256; // threads of every kernel here
+
+__device__ __forceinline__ float block_sum(float v, float *sh)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads(); // (sh may still be read from a previous call)
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3]; // fixed order
+}
+
+// ---- ActNorm ------------------------------------------------------------------------------------------------------
+// one workgroup per (image, channel) plane; reverse: y = x exp(ls) + t  (actnorm.py:40-54)
+__global__ __launch_bounds__(GS_T) void k_actnorm(const float *__restrict__ x, const float *__restrict__ tr,
+                                                  const float *__restrict__ ls, float *__restrict__ y, int C, int HW,
+                                                  int reverse)
+{
+    const size_t plane = blockIdx.x;
+    const int c = (int)(plane % C);
+    const float t = tr[c], l = ls[c];
+    const float sc = reverse ? expf(l) : expf(-l);
+    const float of = reverse ? t : -t * sc; // forward: (x - t) sc = x sc - t sc
+    const float *xp = x + plane * HW;
+    float *yp = y + plane * HW;
+    if ((HW & 3) == 0 && ((((uintptr_t)xp) | ((uintptr_t)yp)) & 15) == 0) {
+        for (int i = threadIdx.x; i < HW / 4; i += GS_T) {
+            const f4 v = ((const f4 *)xp)[i];
+            ((f4 *)yp)[i] = f4{fmaf(v[0], sc, of), fmaf(v[1], sc, of), fmaf(v[2], sc, of), fmaf(v[3], sc, of)};
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += GS_T) yp[i] = fmaf(xp[i], sc, of);
+    }
+}
+// note on rounding: the reference computes (x - t) * exp(-ls); x*sc - t*sc differs by one rounding of t*sc
+// (relative 6e-8 of |t sc|): inside the 1e-5 tolerance of the path, and one FMA instead of two operations.
+
+// logdet[b] = -HW sum_c ls_c (actnorm.py:59-67); one workgroup, B outputs
+__global__ __launch_bounds__(GS_T) void k_actnorm_logdet(const float *__restrict__ ls, float *__restrict__ logdet, int B,
+                                                         int C, int HW)
+{
+    __shared__ float sh[4];
+    float a = 0.f;
+    for (int c = threadIdx.x; c < C; c += GS_T) a += ls[c];
+    const float s = -block_sum(a, sh) * (float)HW;
+    for (int b = threadIdx.x; b < B; b += GS_T) logdet[b] = s;
+}
+
+// backward, stage 1: gx = gy exp(-ls); partial[plane] = {sum gy, sum gy x} over the plane
+__global__ __launch_bounds__(GS_T) void k_actnorm_bwd(const float *__restrict__ gy, const float *__restrict__ x,
+                                                      const float *__restrict__ ls, float *__restrict__ gx,
+                                                      float *__restrict__ partial, int C, int HW)
+{
+    __shared__ float sh[4];
+    const size_t plane = blockIdx.x;
+    const int c = (int)(plane % C);
+    const float sc = expf(-ls[c]);
+    const float *gp = gy + plane * HW, *xp = x + plane * HW;
+    float *op = gx + plane * HW;
+    float s0 = 0.f, s1 = 0.f;
+    if ((HW & 3) == 0 && ((((uintptr_t)gp) | ((uintptr_t)xp) | ((uintptr_t)op)) & 15) == 0) {
+        for (int i = threadIdx.x; i < HW / 4; i += GS_T) {
+            const f4 g = ((const f4 *)gp)[i], v = ((const f4 *)xp)[i];
+            ((f4 *)op)[i] = g * sc;
+            s0 += (g[0] + g[1]) + (g[2] + g[3]);
+            s1 += (g[0] * v[0] + g[1] * v[1]) + (g[2] * v[2] + g[3] * v[3]);
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += GS_T) {
+            const float g = gp[i];
+            op[i] = g * sc;
+            s0 += g;
+            s1 += g * xp[i];
+        }
+    }
+    const float t0 = block_sum(s0, sh), t1 = block_sum(s1, sh);
+    if (threadIdx.x == 0) {
+        partial[2 * plane] = t0;
+        partial[2 * plane + 1] = t1;
+    }
+}
+// stage 2 (one thread per channel, images in order):
+//   gt_c = -sc sum gy;  gls_c = -sc (sum gy x - t sum gy) - HW sum_b g_logdet[b]
+__global__ void k_actnorm_bwd_fin(const float *__restrict__ partial, const float *__restrict__ tr,
+                                  const float *__restrict__ ls, const float *__restrict__ g_logdet,
+                                  float *__restrict__ gt, float *__restrict__ gls, int B, int C, int HW)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s0 = 0.f, s1 = 0.f, sl = 0.f;
+    for (int b = 0; b < B; ++b) {
+        s0 += partial[2 * ((size_t)b * C + c)];
+        s1 += partial[2 * ((size_t)b * C + c) + 1];
+        if (g_logdet) sl += g_logdet[b];
+    }
+    const float sc = expf(-ls[c]);
+    if (gt) gt[c] = -sc * s0;
+    if (gls) gls[c] = -sc * (s1 - tr[c] * s0) - (float)HW * sl;
+}
+
+// data-dependent initialisation (actnorm.py:21-28): mean_c and log(std_c + 1e-8), std unbiased (torch.std).
+// stage 1: per plane {sum x, sum x^2 about the plane's own mean}; stage 2 combines the planes of a channel
+// (Chan's parallel variance: no cancellation of large sums).
+__global__ __launch_bounds__(GS_T) void k_plane_moments(const float *__restrict__ x, float *__restrict__ partial, int HW)
+{
+    __shared__ float sh[4];
+    const size_t plane = blockIdx.x;
+    const float *xp = x + plane * HW;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < HW; i += GS_T) s += xp[i];
+    const float mean = block_sum(s, sh) / (float)HW;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < HW; i += GS_T) {
+        const float d = xp[i] - mean;
+        q += d * d;
+    }
+    const float m2 = block_sum(q, sh);
+    if (threadIdx.x == 0) {
+        partial[2 * plane] = mean;
+        partial[2 * plane + 1] = m2;
+    }
+}
+__global__ void k_actnorm_stats_fin(const float *__restrict__ partial, float *__restrict__ mean, float *__restrict__ logstd,
+                                    int B, int C, int HW)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double n = 0.0, mu = 0.0, m2 = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const double nb = HW, mb = partial[2 * ((size_t)b * C + c)], qb = partial[2 * ((size_t)b * C + c) + 1];
+        const double d = mb - mu, nn = n + nb;
+        mu += d * nb / nn;
+        m2 += qb + d * d * n * nb / nn;
+        n = nn;
+    }
+    mean[c] = (float)mu;
+    logstd[c] = (float)log(sqrt(m2 / (n - 1.0)) + 1e-8);
+}
+
+// ---- Squeeze: y[b][4c + 2dy + dx][h2][w2] = x[b][c][2 h2 + dy][2 w2 + dx]  (squeeze.py:5-13); reverse is the inverse
+// permutation (squeeze.py:16-25).  One workgroup per (image, input channel of the large layout); a thread moves
+// four consecutive columns of the large image (two pixels of each of two small planes).
+__global__ __launch_bounds__(GS_T) void k_squeeze(const float *__restrict__ src, float *__restrict__ dst, int H, int W,
+                                                  int reverse)
+{
+    // H, W: size of the LARGE image (even).  large: [plane][H][W]; small: [plane*4 + 2dy+dx][H/2][W/2]
+    const size_t plane = blockIdx.x;
+    const int H2 = H / 2, W2 = W / 2;
+    const float *lg_r = src + plane * H * W;       // forward reads the large layout
+    float *lg_w = dst + plane * H * W;             // reverse writes it
+    const float *sm_r = src + plane * 4 * H2 * W2; // reverse reads the small layout
+    float *sm_w = dst + plane * 4 * H2 * W2;
+    if ((W & 3) == 0 && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0) {
+        const int Q = W / 4;
+        for (int i = threadIdx.x; i < H * Q; i += GS_T) {
+            const int h = i / Q, q = i % Q, h2 = h >> 1, dy = h & 1;
+            const size_t lo = (size_t)h * W + 4 * q;
+            const size_t s0 = ((size_t)(2 * dy) * H2 + h2) * W2 + 2 * q, s1 = ((size_t)(2 * dy + 1) * H2 + h2) * W2 + 2 * q;
+            if (!reverse) {
+                const f4 v = *(const f4 *)(lg_r + lo);
+                *(f2 *)(sm_w + s0) = f2{v[0], v[2]};
+                *(f2 *)(sm_w + s1) = f2{v[1], v[3]};
+            } else {
+                const f2 a = *(const f2 *)(sm_r + s0), b = *(const f2 *)(sm_r + s1);
+                *(f4 *)(lg_w + lo) = f4{a[0], b[0], a[1], b[1]};
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < H * W; i += GS_T) {
+            const int h = i / W, w = i % W;
+            const size_t so = ((size_t)(2 * (h & 1) + (w & 1)) * H2 + (h >> 1)) * W2 + (w >> 1);
+            if (!reverse) sm_w[so] = lg_r[i];
+            else lg_w[i] = sm_r[so];
+        }
+    }
+}
+
+// ---- Coupling, the affine part (coupling.py:66-98) ------------------------------------------------------------------
+// x, y: (B, C, H, W); h = net(x1): (B, C, H, W) with h_s = h[:, 0::2], t = h[:, 1::2] (C/2 channels each).
+// One workgroup per (image, j), j < C/2: copies plane x1_j, transforms plane x2_j with the channel pair (2j, 2j+1) of h.
+//   forward: z2 = x2 exp(log_s) + t,  partial[b][j] = sum log_s;   reverse: z2 = (x2 - t) exp(-log_s)
+__device__ __forceinline__ float coupling_logs(float hs) { return 2.0f * tanhf(0.5f * hs); }
+
+__global__ __launch_bounds__(GS_T) void k_coupling(const float *__restrict__ x, const float *__restrict__ h,
+                                                   float *__restrict__ y, float *__restrict__ partial, int C, int HW,
+                                                   int reverse)
+{
+    __shared__ float sh[4];
+    const int Ch = C / 2;
+    const int b = blockIdx.x / Ch, j = blockIdx.x % Ch;
+    const float *x1 = x + ((size_t)b * C + j) * HW, *x2 = x + ((size_t)b * C + Ch + j) * HW;
+    const float *hs = h + ((size_t)b * C + 2 * j) * HW, *ht = hs + HW;
+    float *y1 = y + ((size_t)b * C + j) * HW, *y2 = y + ((size_t)b * C + Ch + j) * HW;
+    float acc = 0.f;
+    auto one = [&](float xv, float hsv, float htv, float &out) {
+        const float l = coupling_logs(hsv);
+        out = reverse ? (xv - htv) * expf(-l) : fmaf(xv, expf(l), htv);
+        acc += l;
+    };
+    if ((HW & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)h) | ((uintptr_t)y)) & 15) == 0) {
+        for (int i = threadIdx.x; i < HW / 4; i += GS_T) {
+            if (y1 != x1) ((f4 *)y1)[i] = ((const f4 *)x1)[i];
+            const f4 xv = ((const f4 *)x2)[i], a = ((const f4 *)hs)[i], t = ((const f4 *)ht)[i];
+            f4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float r;
+                one(xv[e], a[e], t[e], r);
+                o[e] = r;
+            }
+            ((f4 *)y2)[i] = o;
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += GS_T) {
+            if (y1 != x1) y1[i] = x1[i];
+            float r;
+            one(x2[i], hs[i], ht[i], r);
+            y2[i] = r;
+        }
+    }
+    if (!reverse && partial) {
+        const float s = block_sum(acc, sh);
+        if (threadIdx.x == 0) partial[(size_t)b * Ch + j] = s;
+    }
+}
+// logdet[b] = sum_j partial[b][j] (channel pairs in order)
+__global__ void k_coupling_logdet(const float *__restrict__ partial, float *__restrict__ logdet, int B, int Ch)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float s = 0.f;
+    for (int j = 0; j < Ch; ++j) s += partial[(size_t)b * Ch + j];
+    logdet[b] = s;
+}
+// backward of the forward direction: given gy (B,C,H,W) and g_logdet (B, may be NULL)
+//   gx1 = gy1 (the part through the net is the caller's: it backpropagates gh through the conditioner)
+//   gx2 = gy2 exp(log_s);  gh_t = gy2;  gh_s = (gy2 x2 exp(log_s) + g_logdet[b]) (1 - tanh^2(h_s/2))
+__global__ __launch_bounds__(GS_T) void k_coupling_bwd(const float *__restrict__ gy, const float *__restrict__ g_logdet,
+                                                       const float *__restrict__ x, const float *__restrict__ h,
+                                                       float *__restrict__ gx, float *__restrict__ gh, int C, int HW)
+{
+    const int Ch = C / 2;
+    const int b = blockIdx.x / Ch, j = blockIdx.x % Ch;
+    const float *g1 = gy + ((size_t)b * C + j) * HW, *g2 = gy + ((size_t)b * C + Ch + j) * HW;
+    const float *x2 = x + ((size_t)b * C + Ch + j) * HW;
+    const float *hs = h + ((size_t)b * C + 2 * j) * HW;
+    float *o1 = gx + ((size_t)b * C + j) * HW, *o2 = gx + ((size_t)b * C + Ch + j) * HW;
+    float *ghs = gh + ((size_t)b * C + 2 * j) * HW, *ght = ghs + HW;
+    const float gl = g_logdet ? g_logdet[b] : 0.f;
+    auto one = [&](float g, float xv, float hsv, float &ox2, float &ohs) {
+        const float th = tanhf(0.5f * hsv), e = expf(2.0f * th);
+        ox2 = g * e;
+        ohs = (g * xv * e + gl) * (1.0f - th * th);
+    };
+    if ((HW & 3) == 0 && ((((uintptr_t)gy) | ((uintptr_t)x) | ((uintptr_t)h) | ((uintptr_t)gx) | ((uintptr_t)gh)) & 15) == 0) {
+        for (int i = threadIdx.x; i < HW / 4; i += GS_T) {
+            const f4 g = ((const f4 *)g2)[i], xv = ((const f4 *)x2)[i], a = ((const f4 *)hs)[i];
+            ((f4 *)o1)[i] = ((const f4 *)g1)[i];
+            ((f4 *)ght)[i] = g;
+            f4 ox, oh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float r0, r1;
+                one(g[e], xv[e], a[e], r0, r1);
+                ox[e] = r0;
+                oh[e] = r1;
+            }
+            ((f4 *)o2)[i] = ox;
+            ((f4 *)ghs)[i] = oh;
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += GS_T) {
+            const float g = g2[i];
+            float r0, r1;
+            one(g, x2[i], hs[i], r0, r1);
+            o1[i] = g1[i];
+            o2[i] = r0;
+            ght[i] = g;
+            ghs[i] = r1;
+        }
+    }
+}
+
+static int check_dims(const char *who, int B, int C, int H, int W)
+{
+    if (B < 0 || C < 1 || H < 1 || W < 1) IFL_FAIL(IFL_EINVAL, "%s: bad shape B=%d C=%d H=%d W=%d", who, B, C, H, W);
+    return IFL_OK;
+}
+
+} // namespace ifl
+
+using namespace ifl;
+
+extern "C" {
+
+size_t ifl_glow_workspace_bytes(int B, int C)
+{
+    return (size_t)2 * (B > 0 ? B : 0) * (C > 0 ? C : 0) * sizeof(float) + 256;
+}
+
+int ifl_actnorm_f32(const float *x, const float *translation, const float *log_scale, float *y, float *logdet, int B,
+                    int C, int H, int W, int reverse, ifl_stream_t stream)
+{
+    clear_error();
+    if (int rc = check_dims("ifl_actnorm_f32", B, C, H, W)) return rc;
+    if (B == 0) return IFL_OK;
+    if (!x || !translation || !log_scale || !y) IFL_FAIL(IFL_EINVAL, "ifl_actnorm_f32: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_actnorm, dim3((unsigned)((size_t)B * C)), dim3(GS_T), 0, s, x, translation, log_scale, y, C, H * W,
+                       reverse);
+    if (logdet && !reverse) hipLaunchKernelGGL(k_actnorm_logdet, dim3(1), dim3(GS_T), 0, s, log_scale, logdet, B, C, H * W);
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+
+int ifl_actnorm_backward_f32(const float *gy, const float *g_logdet, const float *x, const float *translation,
+                             const float *log_scale, float *gx, float *g_translation, float *g_log_scale, int B, int C,
+                             int H, int W, void *ws, size_t ws_bytes, ifl_stream_t stream)
+{
+    clear_error();
+    if (int rc = check_dims("ifl_actnorm_backward_f32", B, C, H, W)) return rc;
+    if (!gy || !x || !translation || !log_scale || !gx) IFL_FAIL(IFL_EINVAL, "ifl_actnorm_backward_f32: null pointer");
+    if (ws_bytes < ifl_glow_workspace_bytes(B, C) || (!ws && B > 0))
+        IFL_FAIL(IFL_EWORKSPACE, "ifl_actnorm_backward_f32: workspace of %zu bytes needed", ifl_glow_workspace_bytes(B, C));
+    hipStream_t s = (hipStream_t)stream;
+    float *partial = (float *)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    if (B > 0)
+        hipLaunchKernelGGL(k_actnorm_bwd, dim3((unsigned)((size_t)B * C)), dim3(GS_T), 0, s, gy, x, log_scale, gx, partial, C,
+                           H * W);
+    hipLaunchKernelGGL(k_actnorm_bwd_fin, dim3((C + 63) / 64), dim3(64), 0, s, partial, translation, log_scale, g_logdet,
+                       g_translation, g_log_scale, B, C, H * W);
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+
+int ifl_actnorm_stats_f32(const float *x, float *mean, float *log_std, int B, int C, int H, int W, void *ws,
+                          size_t ws_bytes, ifl_stream_t stream)
+{
+    clear_error();
+    if (int rc = check_dims("ifl_actnorm_stats_f32", B, C, H, W)) return rc;
+    if (!x || !mean || !log_std || !ws) IFL_FAIL(IFL_EINVAL, "ifl_actnorm_stats_f32: null pointer");
+    if ((size_t)B * H * W < 2) IFL_FAIL(IFL_EINVAL, "ifl_actnorm_stats_f32: needs at least two values per channel");
+    if (ws_bytes < ifl_glow_workspace_bytes(B, C))
+        IFL_FAIL(IFL_EWORKSPACE, "ifl_actnorm_stats_f32: workspace of %zu bytes needed", ifl_glow_workspace_bytes(B, C));
+    hipStream_t s = (hipStream_t)stream;
+    float *partial = (float *)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    hipLaunchKernelGGL(k_plane_moments, dim3((unsigned)((size_t)B * C)), dim3(GS_T), 0, s, x, partial, H * W);
+    hipLaunchKernelGGL(k_actnorm_stats_fin, dim3((C + 63) / 64), dim3(64), 0, s, partial, mean, log_std, B, C, H * W);
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+
+int ifl_squeeze_f32(const float *x, float *y, int B, int C, int H, int W, int reverse, ifl_stream_t stream)
+{
+    clear_error();
+    /* (C, H, W): the LARGE layout -- the input of space_to_depth, the output of depth_to_space */
+    if (int rc = check_dims("ifl_squeeze_f32", B, C, H, W)) return rc;
+    if ((H | W) & 1) IFL_FAIL(IFL_EINVAL, "ifl_squeeze_f32: H=%d, W=%d must be even", H, W);
+    if (B == 0) return IFL_OK;
+    if (!x || !y || x == y) IFL_FAIL(IFL_EINVAL, "ifl_squeeze_f32: null or aliased pointers");
+    hipLaunchKernelGGL(k_squeeze, dim3((unsigned)((size_t)B * C)), dim3(GS_T), 0, (hipStream_t)stream, x, y, H, W, reverse);
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+
+int ifl_coupling_f32(const float *x, const float *h, float *y, float *logdet, int B, int C, int H, int W, int reverse,
+                     void *ws, size_t ws_bytes, ifl_stream_t stream)
+{
+    clear_error();
+    if (int rc = check_dims("ifl_coupling_f32", B, C, H, W)) return rc;
+    if (C & 1) IFL_FAIL(IFL_EINVAL, "ifl_coupling_f32: C=%d must be even", C);
+    if (B == 0) return IFL_OK;
+    if (!x || !h || !y) IFL_FAIL(IFL_EINVAL, "ifl_coupling_f32: null pointer");
+    const bool want_ld = logdet && !reverse;
+    if (want_ld && (!ws || ws_bytes < ifl_glow_workspace_bytes(B, C)))
+        IFL_FAIL(IFL_EWORKSPACE, "ifl_coupling_f32: workspace of %zu bytes needed", ifl_glow_workspace_bytes(B, C));
+    hipStream_t s = (hipStream_t)stream;
+    float *partial = want_ld ? (float *)(((uintptr_t)ws + 255) & ~(uintptr_t)255) : nullptr;
+    hipLaunchKernelGGL(k_coupling, dim3((unsigned)((size_t)B * (C / 2))), dim3(GS_T), 0, s, x, h, y, partial, C, H * W, reverse);
+    if (want_ld) hipLaunchKernelGGL(k_coupling_logdet, dim3((B + 63) / 64), dim3(64), 0, s, partial, logdet, B, C / 2);
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+
+int ifl_coupling_backward_f32(const float *gy, const float *g_logdet, const float *x, const float *h, float *gx, float *gh,
+                              int B, int C, int H, int W, ifl_stream_t stream)
+{
+    clear_error();
+    if (int rc = check_dims("ifl_coupling_backward_f32", B, C, H, W)) return rc;
+    if (C & 1) IFL_FAIL(IFL_EINVAL, "ifl_coupling_backward_f32: C=%d must be even", C);
+    if (B == 0) return IFL_OK;
+    if (!gy || !x || !h || !gx || !gh) IFL_FAIL(IFL_EINVAL, "ifl_coupling_backward_f32: null pointer");
+    hipLaunchKernelGGL(k_coupling_bwd, dim3((unsigned)((size_t)B * (C / 2))), dim3(GS_T), 0, (hipStream_t)stream, gy, g_logdet, x,
+                       h, gx, gh, C, H * W);
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+
+} // extern "C"

@@ -42,6 +42,13 @@ SIGNATURES = {
     "ifl_conv2d_wgrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ifl_conv2d_igrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ifl_conv2d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "ifl_glow_workspace_bytes": (_sz, [_i, _i]),
+    "ifl_actnorm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ifl_actnorm_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "ifl_actnorm_stats_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "ifl_squeeze_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ifl_coupling_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "ifl_coupling_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
 
 
@@ -361,3 +368,124 @@ def conv2d_igrad(gz, w, xshape, padding=(0, 0)):
                                     torch.cuda.current_stream().cuda_stream)
     _check(rc, "ifl_conv2d_igrad_f32")
     return out
+
+
+# ---- Glow-step neighbours of the layer (csrc/glow_step.hip) -------------------------------------
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _glow_ws(B, C, dev):
+    nb = lib().ifl_glow_workspace_bytes(B, C)
+    return _ws(nb, dev), nb
+
+
+def _chk4(x, name):
+    _chk_tensor(x, name)
+    if x.dim() != 4:
+        raise RuntimeError("%s must be (B, C, H, W)" % name)
+    return x.shape
+
+
+def actnorm(x, translation, log_scale, reverse=False, want_logdet=True):
+    """(y, logdet) = ActNorm.forward (inf/layers/actnorm.py:18-38,59-67), or y = ActNorm.reverse (actnorm.py:40-54)."""
+    B, C, H, W = _chk4(x, "input")
+    _chk_tensor(translation, "translation")
+    _chk_tensor(log_scale, "log_scale")
+    if translation.numel() != C or log_scale.numel() != C:
+        raise RuntimeError("translation / log_scale must have %d entries" % C)
+    dev = _same_device(x, translation, log_scale)
+    y = torch.empty_like(x)
+    ld = torch.empty(B, dtype=torch.float32, device=dev) if (want_logdet and not reverse) else None
+    with torch.cuda.device(dev):
+        rc = lib().ifl_actnorm_f32(_ptr(x), _ptr(translation), _ptr(log_scale), _ptr(y), _ptr(ld), B, C, H, W,
+                                   1 if reverse else 0, _stream())
+    _check(rc, "ifl_actnorm_f32")
+    return y if reverse else (y, ld)
+
+
+def actnorm_backward(gy, g_logdet, x, translation, log_scale):
+    """(gx, g_translation, g_log_scale) of ActNorm.forward."""
+    B, C, H, W = _chk4(x, "input")
+    _chk_tensor(gy, "grad_output")
+    if g_logdet is not None:
+        _chk_tensor(g_logdet, "grad_logdet")
+    dev = _same_device(x, gy, translation, log_scale, g_logdet)
+    gx = torch.empty_like(x)
+    gt = torch.empty(C, dtype=torch.float32, device=dev)
+    gls = torch.empty(C, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws, nb = _glow_ws(B, C, dev)
+        rc = lib().ifl_actnorm_backward_f32(_ptr(gy), _ptr(g_logdet), _ptr(x), _ptr(translation), _ptr(log_scale), _ptr(gx),
+                                            _ptr(gt), _ptr(gls), B, C, H, W, _ptr(ws), nb, _stream())
+    _check(rc, "ifl_actnorm_backward_f32")
+    return gx, gt, gls
+
+
+def actnorm_stats(x):
+    """(mean_c, log(std_c + 1e-8)): the data-dependent initialisation of ActNorm (actnorm.py:21-28)."""
+    B, C, H, W = _chk4(x, "input")
+    dev = x.device
+    mean = torch.empty(C, dtype=torch.float32, device=dev)
+    lstd = torch.empty(C, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws, nb = _glow_ws(B, C, dev)
+        rc = lib().ifl_actnorm_stats_f32(_ptr(x), _ptr(mean), _ptr(lstd), B, C, H, W, _ptr(ws), nb, _stream())
+    _check(rc, "ifl_actnorm_stats_f32")
+    return mean, lstd
+
+
+def space_to_depth(x):
+    """inf/layers/squeeze.py:5-13."""
+    B, C, H, W = _chk4(x, "input")
+    y = torch.empty(B, 4 * C, H // 2, W // 2, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib().ifl_squeeze_f32(_ptr(x), _ptr(y), B, C, H, W, 0, _stream())
+    _check(rc, "ifl_squeeze_f32")
+    return y
+
+
+def depth_to_space(x):
+    """inf/layers/squeeze.py:16-25."""
+    B, C4, H2, W2 = _chk4(x, "input")
+    if C4 % 4:
+        raise RuntimeError("depth_to_space needs a multiple of 4 channels")
+    y = torch.empty(B, C4 // 4, 2 * H2, 2 * W2, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib().ifl_squeeze_f32(_ptr(x), _ptr(y), B, C4 // 4, 2 * H2, 2 * W2, 1, _stream())
+    _check(rc, "ifl_squeeze_f32")
+    return y
+
+
+def coupling(x, h, reverse=False, want_logdet=True):
+    """The affine part of Coupling.forward / .reverse (inf/layers/coupling.py:66-98) given h = net(x1)."""
+    B, C, H, W = _chk4(x, "input")
+    _chk_tensor(h, "h")
+    if h.shape != x.shape:
+        raise RuntimeError("h must have the shape of the input")
+    dev = _same_device(x, h)
+    y = torch.empty_like(x)
+    ld = torch.empty(B, dtype=torch.float32, device=dev) if (want_logdet and not reverse) else None
+    with torch.cuda.device(dev):
+        ws, nb = _glow_ws(B, C, dev)
+        rc = lib().ifl_coupling_f32(_ptr(x), _ptr(h), _ptr(y), _ptr(ld), B, C, H, W, 1 if reverse else 0, _ptr(ws), nb,
+                                    _stream())
+    _check(rc, "ifl_coupling_f32")
+    return y if reverse else (y, ld)
+
+
+def coupling_backward(gy, g_logdet, x, h):
+    """(gx_direct, gh) of the affine part of Coupling.forward; the caller backpropagates gh through the net."""
+    B, C, H, W = _chk4(x, "input")
+    _chk_tensor(gy, "grad_output")
+    _chk_tensor(h, "h")
+    if g_logdet is not None:
+        _chk_tensor(g_logdet, "grad_logdet")
+    dev = _same_device(x, gy, h, g_logdet)
+    gx = torch.empty_like(x)
+    gh = torch.empty_like(h)
+    with torch.cuda.device(dev):
+        rc = lib().ifl_coupling_backward_f32(_ptr(gy), _ptr(g_logdet), _ptr(x), _ptr(h), _ptr(gx), _ptr(gh), B, C, H, W,
+                                             _stream())
+    _check(rc, "ifl_coupling_backward_f32")
+    return gx, gh

@@ -237,3 +237,88 @@ def selfnorm_grads(x, W, bw, R, gz, padding):
     wg_inv = (neg + flip_kernel(W) * flip_kernel(multiple)) / 2.0
     bg = gz.reshape(gz.shape[0], gz.shape[1], -1).sum(-1).sum(0) if bw is not None else None
     return input_grad, wg_fwd.astype(x.dtype), bg, wg_inv.astype(x.dtype)
+
+
+# ---- Glow-step neighbours of the layer: numpy restatements, float64 inside -------------------
+def actnorm_forward(x, translation, log_scale):
+    """inf/layers/actnorm.py:18-38,59-67: ((x - t) exp(-ls), -H W sum ls)."""
+    x = np.asarray(x, np.float64)
+    t = np.asarray(translation, np.float64).reshape(1, -1, 1, 1)
+    ls = np.asarray(log_scale, np.float64).reshape(1, -1, 1, 1)
+    y = (x - t) * np.exp(-ls)
+    ld = np.full(x.shape[0], -ls.sum() * x.shape[2] * x.shape[3])
+    return y, ld
+
+
+def actnorm_reverse(y, translation, log_scale):
+    """inf/layers/actnorm.py:40-54."""
+    t = np.asarray(translation, np.float64).reshape(1, -1, 1, 1)
+    ls = np.asarray(log_scale, np.float64).reshape(1, -1, 1, 1)
+    return np.asarray(y, np.float64) * np.exp(ls) + t
+
+
+def actnorm_backward(gy, g_logdet, x, translation, log_scale):
+    """Gradients of actnorm_forward w.r.t. (x, translation, log_scale) for upstream (gy, g_logdet)."""
+    gy = np.asarray(gy, np.float64)
+    y, _ = actnorm_forward(x, translation, log_scale)
+    sc = np.exp(-np.asarray(log_scale, np.float64)).reshape(1, -1, 1, 1)
+    gx = gy * sc
+    gt = -(gy * sc).sum(axis=(0, 2, 3))
+    gls = -(gy * y).sum(axis=(0, 2, 3))
+    if g_logdet is not None:
+        gls = gls - x.shape[2] * x.shape[3] * np.asarray(g_logdet, np.float64).sum()
+    return gx, gt, gls
+
+
+def actnorm_stats(x):
+    """inf/layers/actnorm.py:21-26: mean and log(std + 1e-8) over (B, H, W), std unbiased (torch.std default)."""
+    x = np.asarray(x, np.float64)
+    return x.mean(axis=(0, 2, 3)), np.log(x.std(axis=(0, 2, 3), ddof=1) + 1e-8)
+
+
+def space_to_depth(x):
+    """inf/layers/squeeze.py:5-13."""
+    B, C, H, W = x.shape
+    x = x.reshape(B, C, H // 2, 2, W // 2, 2).transpose(0, 1, 3, 5, 2, 4)
+    return np.ascontiguousarray(x).reshape(B, C * 4, H // 2, W // 2)
+
+
+def depth_to_space(x):
+    """inf/layers/squeeze.py:16-25."""
+    B, C, H, W = x.shape
+    x = x.reshape(B, C // 4, 2, 2, H, W).transpose(0, 1, 4, 2, 5, 3)
+    return np.ascontiguousarray(x).reshape(B, C // 4, H * 2, W * 2)
+
+
+def _coupling_parts(x, h):
+    x = np.asarray(x, np.float64)
+    h = np.asarray(h, np.float64)
+    ch = x.shape[1] // 2
+    return x[:, :ch], x[:, ch:], 2.0 * np.tanh(h[:, 0::2] / 2.0), h[:, 1::2]
+
+
+def coupling_forward(x, h):
+    """inf/layers/coupling.py:66-89 given h = net(x1): (cat(x1, x2 exp(log_s) + t), sum log_s)."""
+    x1, x2, log_s, t = _coupling_parts(x, h)
+    return np.concatenate([x1, x2 * np.exp(log_s) + t], axis=1), log_s.reshape(len(x1), -1).sum(-1)
+
+
+def coupling_reverse(y, h):
+    """inf/layers/coupling.py:92-98."""
+    x1, x2, log_s, t = _coupling_parts(y, h)
+    return np.concatenate([x1, (x2 - t) * np.exp(-log_s)], axis=1)
+
+
+def coupling_backward(gy, g_logdet, x, h):
+    """Gradients of coupling_forward w.r.t. x (direct part: h held fixed) and h."""
+    gy = np.asarray(gy, np.float64)
+    x1, x2, log_s, t = _coupling_parts(x, h)
+    ch = x1.shape[1]
+    g1, g2 = gy[:, :ch], gy[:, ch:]
+    e = np.exp(log_s)
+    gl = 0.0 if g_logdet is None else np.asarray(g_logdet, np.float64).reshape(-1, 1, 1, 1)
+    th = log_s / 2.0
+    gh = np.empty(np.asarray(h).shape, np.float64)
+    gh[:, 0::2] = (g2 * x2 * e + gl) * (1.0 - th * th)
+    gh[:, 1::2] = g2
+    return np.concatenate([g1, g2 * e], axis=1), gh

@@ -1,0 +1,47 @@
+"""CPU: the oracle's restatements of ActNorm / Squeeze / Coupling (oracle/oracle.py) against the golden vectors the
+reference's own layers produced (tests/golden/make_golden_glow.py)."""
+import numpy as np
+import pytest
+
+from conftest import golden_files, load_golden, rel_err
+
+TOL = 2e-6  # the fixtures are fp32 results of fp32 torch code; the oracle computes in fp64
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as o
+    return o
+
+
+@pytest.mark.parametrize("path", golden_files("actnorm_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_actnorm(oracle, path):
+    g = load_golden(path)
+    if int(g["init_from_data"]):
+        mean, lstd = oracle.actnorm_stats(g["x"])
+        assert rel_err(mean, g["translation"]) < TOL and rel_err(lstd, g["log_scale"]) < TOL
+    y, ld = oracle.actnorm_forward(g["x"], g["translation"], g["log_scale"])
+    assert rel_err(y, g["y"]) < TOL and rel_err(ld, g["logdet"]) < TOL
+    assert rel_err(oracle.actnorm_reverse(g["y"], g["translation"], g["log_scale"]), g["x_rev"]) < TOL
+    gx, gt, gls = oracle.actnorm_backward(g["gy"], g["gld"], g["x"], g["translation"], g["log_scale"])
+    assert rel_err(gx, g["gx"]) < TOL and rel_err(gt, g["g_translation"]) < 1e-5 and rel_err(gls, g["g_log_scale"]) < 1e-5
+
+
+@pytest.mark.parametrize("path", golden_files("squeeze_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_squeeze(oracle, path):
+    g = load_golden(path)
+    assert np.array_equal(oracle.space_to_depth(g["x"]), g["y"])
+    assert np.array_equal(oracle.depth_to_space(g["y"]), g["x_back"]) and np.array_equal(g["x_back"], g["x"])
+
+
+@pytest.mark.parametrize("path", golden_files("coupling_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_coupling(oracle, path):
+    g = load_golden(path)
+    y, ld = oracle.coupling_forward(g["x"], g["h"])
+    assert rel_err(y, g["y"]) < TOL and rel_err(ld, g["logdet"]) < 1e-5
+    assert rel_err(oracle.coupling_reverse(g["y"], g["h"]), g["x_rev"]) < 1e-5
+    gx, gh = oracle.coupling_backward(g["gy"], g["gld"], g["x"], g["h"])
+    assert rel_err(gh, g["gh"]) < 1e-5
+    # the direct part of dL/dx: the second half of the channels receives nothing through the net
+    ch = g["x"].shape[1] // 2
+    assert rel_err(gx[:, ch:], g["gx_total"][:, ch:]) < 1e-5

@@ -1,0 +1,199 @@
+"""GPU: ActNorm / Squeeze / Coupling of libinvflow_hip (csrc/glow_step.hip) through the C ABI
+against the reference's golden vectors and the oracle, and the host layers built on them against the reference
+layers' recorded outputs and gradients."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_files, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def H():
+    import invflow_hip
+    invflow_hip.lib()
+    return invflow_hip
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as o
+    return o
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("path", golden_files("actnorm_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_golden_actnorm(H, path):
+    g = load_golden(path)
+    x, t, ls = dev(g["x"]), dev(g["translation"]), dev(g["log_scale"])
+    if int(g["init_from_data"]):
+        mean, lstd = H.actnorm_stats(x)
+        assert rel_err(host(mean), g["translation"]) < TOL and rel_err(host(lstd), g["log_scale"]) < TOL
+    y, ld = H.actnorm(x, t, ls)
+    assert rel_err(host(y), g["y"]) < TOL and rel_err(host(ld), g["logdet"]) < TOL
+    assert rel_err(host(H.actnorm(dev(g["y"]), t, ls, reverse=True)), g["x_rev"]) < TOL
+    gx, gt, gls = H.actnorm_backward(dev(g["gy"]), dev(g["gld"]), x, t, ls)
+    assert rel_err(host(gx), g["gx"]) < TOL and rel_err(host(gt), g["g_translation"]) < TOL
+    assert rel_err(host(gls), g["g_log_scale"]) < TOL
+
+
+@pytest.mark.parametrize("path", golden_files("squeeze_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_golden_squeeze(H, path):
+    g = load_golden(path)
+    y = H.space_to_depth(dev(g["x"]))
+    assert np.array_equal(host(y), g["y"])
+    assert np.array_equal(host(H.depth_to_space(y)), g["x"])
+
+
+@pytest.mark.parametrize("path", golden_files("coupling_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_golden_coupling(H, path):
+    g = load_golden(path)
+    x, h = dev(g["x"]), dev(g["h"])
+    y, ld = H.coupling(x, h)
+    assert rel_err(host(y), g["y"]) < TOL and rel_err(host(ld), g["logdet"]) < TOL
+    assert rel_err(host(H.coupling(dev(g["y"]), h, reverse=True)), g["x_rev"]) < TOL
+    gx, gh = H.coupling_backward(dev(g["gy"]), dev(g["gld"]), x, h)
+    ch = x.shape[1] // 2
+    assert rel_err(host(gh), g["gh"]) < TOL
+    assert rel_err(host(gx)[:, ch:], g["gx_total"][:, ch:]) < TOL and np.array_equal(host(gx)[:, :ch], g["gy"][:, :ch])
+
+
+SHAPES = [(5, 7, 7, 7), (3, 4, 9, 6), (16, 64, 32, 32), (2, 256, 8, 8), (1, 2, 2, 2), (7, 10, 28, 28)]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_against_oracle(H, oracle, shape):
+    """ragged planes (H*W not a multiple of 4: the scalar path), one-pixel-row images, the north-star plane size and a
+    wide layer: every op against the fp64 restatement; in-place forms; empty batch."""
+    B, C, Hh, Ww = shape
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal(shape).astype(np.float32) * 2 + 0.5
+    t = rng.standard_normal(C).astype(np.float32)
+    ls = (rng.standard_normal(C) * 0.7).astype(np.float32)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    gld = rng.standard_normal(B).astype(np.float32)
+    y, ld = H.actnorm(dev(x), dev(t), dev(ls))
+    y_o, ld_o = oracle.actnorm_forward(x, t, ls)
+    assert rel_err(host(y), y_o) < TOL and rel_err(host(ld), ld_o) < TOL
+    assert rel_err(host(H.actnorm(y, dev(t), dev(ls), reverse=True)), x) < TOL  # round trip
+    gx, gt, gls = H.actnorm_backward(dev(gy), dev(gld), dev(x), dev(t), dev(ls))
+    gx_o, gt_o, gls_o = oracle.actnorm_backward(gy, gld, x, t, ls)
+    assert rel_err(host(gx), gx_o) < TOL and rel_err(host(gt), gt_o) < TOL and rel_err(host(gls), gls_o) < TOL
+    if B * Hh * Ww > 1:
+        m, s = H.actnorm_stats(dev(x))
+        m_o, s_o = oracle.actnorm_stats(x)
+        assert rel_err(host(m), m_o) < TOL and rel_err(host(s), s_o) < TOL
+    if Hh % 2 == 0 and Ww % 2 == 0:
+        q = H.space_to_depth(dev(x))
+        assert np.array_equal(host(q), oracle.space_to_depth(x))
+        assert np.array_equal(host(H.depth_to_space(q)), x)
+    if C % 2 == 0:
+        h = rng.standard_normal(shape).astype(np.float32) * 1.5
+        z, zl = H.coupling(dev(x), dev(h))
+        z_o, zl_o = oracle.coupling_forward(x, h)
+        assert rel_err(host(z), z_o) < TOL and rel_err(host(zl), zl_o) < TOL
+        assert rel_err(host(H.coupling(z, dev(h), reverse=True)), x) < TOL
+        gx, gh = H.coupling_backward(dev(gy), dev(gld), dev(x), dev(h))
+        gx_o, gh_o = oracle.coupling_backward(gy, gld, x, h)
+        assert rel_err(host(gx), gx_o) < TOL and rel_err(host(gh), gh_o) < TOL
+
+
+def test_errors_and_empty(H):
+    e = torch.empty(0, 4, 6, 6, device="cuda")
+    p = torch.zeros(4, device="cuda")
+    y, ld = H.actnorm(e, p, p)
+    assert y.shape == e.shape and ld.shape == (0,)
+    with pytest.raises(RuntimeError, match="must be even"):
+        H.space_to_depth(torch.zeros(1, 2, 5, 6, device="cuda"))
+    with pytest.raises(RuntimeError, match="must be even"):
+        H.coupling(torch.zeros(1, 3, 4, 4, device="cuda"), torch.zeros(1, 3, 4, 4, device="cuda"))
+    with pytest.raises(RuntimeError):
+        H.actnorm(torch.zeros(1, 3, 4, 4, device="cuda"), torch.zeros(2, device="cuda"), torch.zeros(3, device="cuda"))
+
+
+# ---- host layers (inf/layers/actnorm.py, squeeze.py, coupling.py of this package) ----------------------------------
+def test_actnorm_layer(H):
+    from inf.layers.actnorm import ActNorm
+    g = load_golden(golden_files("actnorm_b4c5_7x5_datainit")[0])
+    layer = ActNorm(5).cuda()
+    x = dev(g["x"]).requires_grad_(True)
+    y, ld = layer(x)  # first call: data-dependent initialisation
+    assert int(layer.initialized) == 1
+    assert rel_err(host(layer.translation), g["translation"]) < TOL and rel_err(host(layer.log_scale), g["log_scale"]) < TOL
+    assert rel_err(host(y), g["y"]) < TOL and rel_err(host(ld), g["logdet"]) < TOL
+    ((y * dev(g["gy"])).sum() + (ld * dev(g["gld"])).sum()).backward()
+    assert rel_err(host(x.grad), g["gx"]) < TOL
+    assert rel_err(host(layer.translation.grad), g["g_translation"]) < TOL
+    assert rel_err(host(layer.log_scale.grad), g["g_log_scale"]) < TOL
+    with torch.no_grad():
+        assert rel_err(host(layer.reverse(y.detach())), g["x_rev"]) < TOL
+    assert rel_err(host(layer.logdet(x)), g["logdet"]) < TOL
+
+
+def test_squeeze_layer(H):
+    from inf.layers.squeeze import Squeeze, UnSqueeze
+    g = load_golden(golden_files("squeeze_b2c3_8x12")[0])
+    x = dev(g["x"]).requires_grad_(True)
+    y, ld = Squeeze()(x)
+    assert np.array_equal(host(y), g["y"]) and float(ld.abs().sum()) == 0.0 and ld.shape == (2,)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    assert torch.equal(x.grad, UnSqueeze()(w)[0])  # the gradient of a permutation is the inverse permutation
+    assert np.array_equal(host(Squeeze().reverse(y.detach())), g["x"])
+
+
+@pytest.mark.parametrize("path", golden_files("coupling_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_coupling_layer(H, path):
+    """the reference layer's state_dict loads as is; outputs, the FULL input gradient (direct part + the part through
+    the conditioner) and the conditioner's parameter gradients follow"""
+    from inf.layers.coupling import Coupling
+    g = load_golden(path)
+    B, C, Hh, Ww = g["x"].shape
+    layer = Coupling((C, Hh, Ww), width=int(g["width"]))
+    sd = {k.replace("__", "."): torch.from_numpy(v) for k, v in g.items() if k.startswith("net__")}
+    layer.load_state_dict(sd)
+    layer = layer.cuda()
+    x = dev(g["x"]).requires_grad_(True)
+    y, ld = layer(x)
+    assert rel_err(host(y), g["y"]) < TOL and rel_err(host(ld), g["logdet"]) < TOL
+    ((y * dev(g["gy"])).sum() + (ld * dev(g["gld"])).sum()).backward()
+    assert rel_err(host(x.grad), g["gx_total"]) < 2e-5
+    with torch.no_grad():
+        assert rel_err(host(layer.reverse(y.detach())), g["x_rev"]) < TOL
+    # torch-expression path of the same layer (CPU tensors) gives the same parameter gradients
+    ref = Coupling((C, Hh, Ww), width=int(g["width"]))
+    ref.load_state_dict(sd)
+    xc = torch.from_numpy(g["x"]).requires_grad_(True)
+    yc, lc = ref(xc)
+    ((yc * torch.from_numpy(g["gy"])).sum() + (lc * torch.from_numpy(g["gld"])).sum()).backward()
+    for (k, p), (_, q) in zip(layer.named_parameters(), ref.named_parameters()):
+        if q.grad is not None:
+            assert rel_err(host(p.grad), q.grad.numpy()) < 1e-4, k
+
+
+def test_full_size_round_trips(H):
+    """north-star activation size (128, 64, 32, 32): forward then reverse of each op is the identity to fp32 rounding;
+    log-dets add up as the definitions say"""
+    torch.manual_seed(0)
+    x = torch.randn(128, 64, 32, 32, device="cuda")
+    t, ls = torch.randn(64, device="cuda"), torch.randn(64, device="cuda") * 0.3
+    y, ld = H.actnorm(x, t, ls)
+    assert float((H.actnorm(y, t, ls, reverse=True) - x).abs().max()) < 1e-5
+    assert abs(float(ld[0]) + 1024 * float(ls.double().sum())) < 1e-2 and float(ld.max() - ld.min()) == 0.0
+    q = H.space_to_depth(x)
+    assert q.shape == (128, 256, 16, 16) and torch.equal(H.depth_to_space(q), x)
+    h = torch.randn_like(x)
+    z, zl = H.coupling(x, h)
+    assert float((H.coupling(z, h, reverse=True) - x).abs().max()) < 2e-5
+    ref = (2 * torch.tanh(h[:, ::2].double() / 2)).flatten(1).sum(-1)
+    assert float(((zl.double() - ref).abs() / ref.abs().clamp_min(1.0)).max()) < 1e-5

@@ -96,23 +96,29 @@ __global__ __launch_bounds__(GS_T) void k_actnorm_bwd(const float *__restrict__ 
         partial[2 * plane + 1] = t1;
     }
 }
-// stage 2 (one thread per channel, images in order):
+// stage 2 (one wave per channel: lane i sums the images i, i+64, ... in order, then a fixed shuffle tree):
 //   gt_c = -sc sum gy;  gls_c = -sc (sum gy x - t sum gy) - HW sum_b g_logdet[b]
-__global__ void k_actnorm_bwd_fin(const float *__restrict__ partial, const float *__restrict__ tr,
-                                  const float *__restrict__ ls, const float *__restrict__ g_logdet,
-                                  float *__restrict__ gt, float *__restrict__ gls, int B, int C, int HW)
+__global__ __launch_bounds__(64) void k_actnorm_bwd_fin(const float *__restrict__ partial, const float *__restrict__ tr,
+                                                        const float *__restrict__ ls, const float *__restrict__ g_logdet,
+                                                        float *__restrict__ gt, float *__restrict__ gls, int B, int C, int HW)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;
     float s0 = 0.f, s1 = 0.f, sl = 0.f;
-    for (int b = 0; b < B; ++b) {
+    for (int b = threadIdx.x; b < B; b += 64) {
         s0 += partial[2 * ((size_t)b * C + c)];
         s1 += partial[2 * ((size_t)b * C + c) + 1];
         if (g_logdet) sl += g_logdet[b];
     }
-    const float sc = expf(-ls[c]);
-    if (gt) gt[c] = -sc * s0;
-    if (gls) gls[c] = -sc * (s1 - tr[c] * s0) - (float)HW * sl;
+    for (int o = 32; o > 0; o >>= 1) {
+        s0 += __shfl_down(s0, o, 64);
+        s1 += __shfl_down(s1, o, 64);
+        sl += __shfl_down(sl, o, 64);
+    }
+    if (threadIdx.x == 0) {
+        const float sc = expf(-ls[c]);
+        if (gt) gt[c] = -sc * s0;
+        if (gls) gls[c] = -sc * (s1 - tr[c] * s0) - (float)HW * sl;
+    }
 }
 
 // data-dependent initialisation (actnorm.py:21-28): mean_c and log(std_c + 1e-8), std unbiased (torch.std).
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(GS_T) void k_plane_moments(const float *__restrict_
     for (int i = threadIdx.x; i < HW; i += GS_T) s += xp[i];
     const float mean = block_sum(s, sh) / (float)HW;
     float q = 0.f;
-    for (int i = threadIdx.x; i < HW; i += GS_T) {
+    for (int i = threadIdx.x; i < HW; i += GS_T) { // (second read of the plane: L2-resident, 4 KB at 32x32)
         const float d = xp[i] - mean;
         q += d * d;
     }
@@ -344,8 +350,8 @@ int ifl_actnorm_backward_f32(const float *gy, const float *g_logdet, const float
     if (B > 0)
         hipLaunchKernelGGL(k_actnorm_bwd, dim3((unsigned)((size_t)B * C)), dim3(GS_T), 0, s, gy, x, log_scale, gx, partial, C,
                            H * W);
-    hipLaunchKernelGGL(k_actnorm_bwd_fin, dim3((C + 63) / 64), dim3(64), 0, s, partial, translation, log_scale, g_logdet,
-                       g_translation, g_log_scale, B, C, H * W);
+    hipLaunchKernelGGL(k_actnorm_bwd_fin, dim3(C), dim3(64), 0, s, partial, translation, log_scale, g_logdet, g_translation,
+                       g_log_scale, B, C, H * W);
     IFL_HIP(hipGetLastError());
     return IFL_OK;
 }

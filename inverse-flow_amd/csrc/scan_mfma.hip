@@ -114,7 +114,7 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
                                          const half8 *__restrict__ apack, const int H, const int W, const int rh,
                                          const int rw, int *__restrict__ flags, const float *__restrict__ wf32,
                                          const Geom &geom, unsigned *__restrict__ amax, const SplitState &sp, const int b,
-                                         const int part)
+                                         const int part, const int skip_plain = 0)
 {
     static_assert(!SPLIT || NTILE == 1, "a split scan's workgroup owns one row tile");
     using Cfg = ScanCfg<C, KH, KW, NTILE>;
@@ -863,7 +863,8 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
             sweep(std::false_type{}, std::integral_constant<int, 1>{});
         }
     } else {
-        sweep(std::false_type{}, PWhole{});
+        // (skip_plain: the caller knows that the plain sweep leaves the fp16 range -- the redo of a split scan)
+        if (!skip_plain) sweep(std::false_type{}, PWhole{});
     }
 
 #ifdef IFL_STAMPS
@@ -896,7 +897,8 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
         // redoes it whole (scaled retry, fp32 body).  The upper half tells it through a verdict granule; if its own
         // rows are void it first writes its L2's dirty lines back (agent-scope release), so that they cannot land on
         // top of the redone rows later (the two workgroups may sit on XCDs with separate L2s).
-        int bad = __syncthreads_or((rmax < 6.0e4f ? 0 : 1) | dead); // (every wave is behind its vmcnt(0): sweep end)
+        // bit 0: left the fp16 range; bit 1: the hand-off failed
+        int bad = __syncthreads_or((rmax < 6.0e4f ? 0 : 1) | (dead << 1)); // (every wave is behind its vmcnt(0): sweep end)
         if (amax) {
             for (int o = 32; o > 0; o >>= 1) zmax = fmaxf(zmax, __shfl_down(zmax, o, 64));
             if (lane == 0) atomicMax(amax, __float_as_uint(zmax));
@@ -922,12 +924,12 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
                 }
                 __builtin_amdgcn_s_sleep(2);
             }
-            bad |= pv != 1; // (no verdict in time counts as void)
+            bad |= pv == 1 ? 0 : (pv == 2 ? 1 : 2); // (no verdict in time counts as a failed hand-off)
             bad = __syncthreads_or(bad);
         }
         return bad;
     } else {
-    int redo = __syncthreads_or(rmax < 6.0e4f ? 0 : 1);
+    int redo = skip_plain ? 1 : __syncthreads_or(rmax < 6.0e4f ? 0 : 1);
     int attempts = 0;
     while (redo && attempts < 1) {
         ++attempts;
@@ -1006,7 +1008,8 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_split(const float *__res
     if (part == 0) return;
     if (bad) {
         __syncthreads();
-        scan_body<C, KH, KW, 2, PAD, false>(xin, zout, apack, H, W, rh, rw, flags, wf32, geom, amax, sp, b, 0);
+        // (void because of the range only: straight to the scaled sweep)
+        scan_body<C, KH, KW, 2, PAD, false>(xin, zout, apack, H, W, rh, rw, flags, wf32, geom, amax, sp, b, 0, bad == 1);
     } else if (threadIdx.x == 0) {
         flags[b] = 0;
     }

@@ -334,7 +334,8 @@ def _no_split(on):
         os.environ.pop("IFL_NO_SPLIT", None)
 
 
-@pytest.mark.parametrize("shape", [(128, 64, 32, 32, 3), (128, 32, 32, 16, 3), (40, 64, 24, 32, 2), (13, 48, 32, 32, 3)],
+@pytest.mark.parametrize("shape", [(128, 64, 32, 32, 3), (128, 32, 32, 16, 3), (40, 64, 24, 32, 2), (13, 48, 32, 32, 3),
+                                   (5, 64, 17, 4, 3), (9, 20, 20, 8, 2), (3, 32, 31, 12, 3)],
                          ids=lambda s: "B%d_C%d_%dx%d_K%d" % s)
 def test_split_scan_equals_whole_image_scan(H, shape):
     """Two workgroups per image (k_scan_split: mailbox hand-off of rows 14, 15) against one workgroup per image, at the

@@ -337,7 +337,7 @@ static int dw_impl(const float *z, const float *dx, float *dw, int B, int C, int
                                      dkw, amax_dx, amax_z, s);
         IFL_FAIL(IFL_EWORKSPACE, "ifl_dw_f32: workspace too small: need %zu bytes, have %zu", cv.off, cv.cap);
     }
-    if (wgrad_small_supported(B, C, H, W)) {
+    if (wgrad_small_supported(B, C, H, W, KH, KW)) {
         Carver cv(ws, ws_bytes);
         void *wws = cv.take<char>(wgrad_small_workspace_bytes(B, C, KH, KW));
         if (cv.ok())

@@ -119,7 +119,7 @@ int launch_conv_mfma(const float *in, const float *w, const float *bias, float *
 // ---- small layers (small_layers.hip): C <= 8, image + result resident in LDS ------------------------------------
 bool scan_resident_supported(const Geom &g);
 int launch_scan_resident(const float *x, const float *wf, float *z, const Geom &g, int rh, int rw, hipStream_t s);
-bool wgrad_small_supported(int B, int C, int H, int W);
+bool wgrad_small_supported(int B, int C, int H, int W, int KH, int KW);
 size_t wgrad_small_workspace_bytes(int B, int C, int KH, int KW);
 int launch_wgrad_small(const float *gz, const float *x, float *dw, void *ws, int B, int C, int H, int W, int KH, int KW,
                        int pt, int pl, float scale, int mask_mode, int mkh, int mkw, hipStream_t s);

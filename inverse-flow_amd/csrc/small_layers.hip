@@ -75,45 +75,81 @@ int launch_scan_resident(const float *x, const float *wf, float *z, const Geom &
 }
 
 // partial[b][co][ci][t] = sum_{oh,ow} gz[b][co][oh][ow] * x[b][ci][oh-pt+kh][ow-pl+kw]   (same-size layers)
+// One workgroup per image, both tensors of the image in LDS: gz as [co][H*W], x with a zero halo of the kernel's reach
+// as [ci][(H+KH-1)(W+KW-1)] (no bounds checks in the loop); plane pitches odd, so that the threads of a wave -- same
+// co, consecutive ci -- read one broadcast word of gz and conflict-free words of x.  A thread owns (co, ci) pairs and
+// keeps the KH*KW sums of a pair in registers.
+template <int KH, int KW>
 __global__ __launch_bounds__(256) void k_wgrad_batchpar(const float *__restrict__ gz, const float *__restrict__ x,
-                                                        float *__restrict__ partial, int C, int H, int W, int KH, int KW,
-                                                        int pt, int pl)
+                                                        float *__restrict__ partial, int C, int H, int W, int pt, int pl)
 {
     extern __shared__ float smem[];
-    const int HW = H * W, n = C * HW, NT = KH * KW, NO = C * C * NT;
-    float *gs = smem, *xs = smem + n;
+    constexpr int NT = KH * KW;
+    const int HW = H * W, PG = HW | 1, WH = W + KW - 1, HH = H + KH - 1, PX = (HH * WH) | 1;
+    float *gs = smem, *xs = smem + C * PG;
     const int b = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < n; i += 256) {
-        gs[i] = gz[(size_t)b * n + i];
-        xs[i] = x[(size_t)b * n + i];
+    for (int i = tid; i < C * PX; i += 256) xs[i] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < C * HW; i += 256) {
+        const int c = i / HW, r = i % HW, h = r / W, w = r % W;
+        gs[c * PG + r] = gz[(size_t)b * C * HW + i];
+        // x[h][w] is read by output (oh, ow) through tap (kh, kw) at h = oh - pt + kh: stored at (h + pt, w + pl)
+        xs[c * PX + (h + pt) * WH + (w + pl)] = x[(size_t)b * C * HW + i];
     }
     __syncthreads();
-    for (int o = tid; o < NO; o += 256) {
-        const int t = o % NT, ci = (o / NT) % C, co = o / (NT * C);
-        const int kh = t / KW, kw = t % KW;
-        // rows / columns of the output for which the tap reads inside the image
-        const int oh0 = pt - kh > 0 ? pt - kh : 0, oh1 = H + pt - kh < H ? H + pt - kh : H;
-        const int ow0 = pl - kw > 0 ? pl - kw : 0, ow1 = W + pl - kw < W ? W + pl - kw : W;
-        float acc = 0.f;
-        for (int oh = oh0; oh < oh1; ++oh) {
-            const float *gp = gs + co * HW + oh * W, *xp = xs + ci * HW + (oh - pt + kh) * W + (kw - pl);
-            for (int ow = ow0; ow < ow1; ++ow) acc = fmaf(gp[ow], xp[ow], acc);
+    // fewer pairs than threads: the image rows are cut into S segments per pair, summed afterwards in order
+    const int CC = C * C, S = CC >= 256 ? 1 : (256 / CC < H ? 256 / CC : H);
+    float *red = xs + C * PX; // [pair][segment][tap], only when S > 1
+    for (int it = tid; it < CC * S; it += 256) {
+        const int pr = it / S, sg = it % S;
+        const int co = pr / C, ci = pr % C;
+        const int oh0 = sg * H / S, oh1 = (sg + 1) * H / S;
+        const float *gp = gs + co * PG, *xp = xs + ci * PX;
+        float acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = 0.f;
+        for (int oh = oh0; oh < oh1; ++oh)
+            for (int ow = 0; ow < W; ++ow) {
+                const float g = gp[oh * W + ow];
+#pragma unroll
+                for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < KW; ++kw) acc[kh * KW + kw] = fmaf(g, xp[(oh + kh) * WH + ow + kw], acc[kh * KW + kw]);
+            }
+        float *out = S > 1 ? red + (size_t)it * NT : partial + ((size_t)b * CC + pr) * NT;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) out[t] = acc[t];
+    }
+    if (S > 1) {
+        __syncthreads();
+        for (int o = tid; o < CC * NT; o += 256) {
+            const int pr = o / NT, t = o % NT;
+            float a = 0.f;
+            for (int sg = 0; sg < S; ++sg) a += red[((size_t)pr * S + sg) * NT + t];
+            partial[(size_t)b * CC * NT + o] = a;
         }
-        partial[(size_t)b * NO + o] = acc;
     }
 }
 
-// dw[o] = scale * sum_b partial[b][o] (fixed order), masked like k_wgrad_direct
+// dw[o] = scale * sum_b partial[b][o], masked like k_wgrad_direct.  64 outputs per workgroup; the images are summed in
+// four interleaved sequences (b = s, s+4, ...), combined as (s0 + s1) + (s2 + s3): a fixed order, deterministic.
 __global__ __launch_bounds__(256) void k_wgrad_batchred(const float *__restrict__ partial, float *__restrict__ dw, int B,
                                                         int C, int KH, int KW, float scale, int mask_mode, int mkh, int mkw)
 {
+    __shared__ float sh[4][64];
     const int NT = KH * KW, NO = C * C * NT;
-    const int o = blockIdx.x * 256 + threadIdx.x;
-    if (o >= NO) return;
+    const int ol = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int o = blockIdx.x * 64 + ol;
     float acc = 0.f;
-    for (int b = 0; b < B; ++b) acc += partial[(size_t)b * NO + o];
+    if (o < NO) {
+#pragma unroll 4
+        for (int b = seg; b < B; b += 4) acc += partial[(size_t)b * NO + o];
+    }
+    sh[seg][ol] = acc;
+    __syncthreads();
+    if (seg != 0 || o >= NO) return;
     const int t = o % NT, ci = (o / NT) % C, co = o / (NT * C);
-    float val = acc * scale;
+    float val = ((sh[0][ol] + sh[1][ol]) + (sh[2][ol] + sh[3][ol])) * scale;
     if (mask_mode && t / KW == mkh && t % KW == mkw) {
         if (mask_mode == 1 && ci >= co) val = 0.f;
         if (mask_mode == 2 && ci > co) val = 0.f;
@@ -123,17 +159,33 @@ __global__ __launch_bounds__(256) void k_wgrad_batchred(const float *__restrict_
 
 size_t wgrad_small_workspace_bytes(int B, int C, int KH, int KW) { return (size_t)B * C * C * KH * KW * sizeof(float) + 256; }
 
-bool wgrad_small_supported(int B, int C, int H, int W) { return B >= 1 && C <= 8 && (size_t)2 * C * H * W * sizeof(float) <= 64 * 1024; }
+static size_t wgrad_small_lds_bytes(int C, int H, int W, int KH, int KW)
+{
+    const size_t red = C * C < 256 ? (size_t)256 * KH * KW : 0; // segment sums of the layers with few (co, ci) pairs
+    return ((size_t)C * (((H * W) | 1) + (((H + KH - 1) * (W + KW - 1)) | 1)) + red) * sizeof(float);
+}
+
+// one workgroup per image pays as long as both tensors of the image fit the LDS and a thread's (co, ci) pairs are few:
+// the small layers of the reference models (C = 1..8 MNIST, C = 12 / 24 / 48 ImageNet-32 and CIFAR levels that the
+// MFMA kernel does not cover).  K in {2x2, 3x3} (register-resident tap sums).
+bool wgrad_small_supported(int B, int C, int H, int W, int KH, int KW)
+{
+    if (!((KH == 2 && KW == 2) || (KH == 3 && KW == 3))) return false;
+    return B >= 1 && C <= 48 && wgrad_small_lds_bytes(C, H, W, KH, KW) <= 64 * 1024;
+}
 
 int launch_wgrad_small(const float *gz, const float *x, float *dw, void *ws, int B, int C, int H, int W, int KH, int KW,
                        int pt, int pl, float scale, int mask_mode, int mkh, int mkw, hipStream_t s)
 {
     float *partial = (float *)ws;
-    hipLaunchKernelGGL(k_wgrad_batchpar, dim3(B), dim3(256), (size_t)2 * C * H * W * sizeof(float), s, gz, x, partial, C, H, W,
-                       KH, KW, pt, pl);
+    const size_t lds = wgrad_small_lds_bytes(C, H, W, KH, KW);
+    if (KH == 2)
+        hipLaunchKernelGGL((k_wgrad_batchpar<2, 2>), dim3(B), dim3(256), lds, s, gz, x, partial, C, H, W, pt, pl);
+    else
+        hipLaunchKernelGGL((k_wgrad_batchpar<3, 3>), dim3(B), dim3(256), lds, s, gz, x, partial, C, H, W, pt, pl);
     IFL_HIP(hipGetLastError());
     const int NO = C * C * KH * KW;
-    hipLaunchKernelGGL(k_wgrad_batchred, dim3((NO + 255) / 256), dim3(256), 0, s, partial, dw, B, C, KH, KW, scale, mask_mode,
+    hipLaunchKernelGGL(k_wgrad_batchred, dim3((NO + 63) / 64), dim3(256), 0, s, partial, dw, B, C, KH, KW, scale, mask_mode,
                        mkh, mkw);
     IFL_HIP(hipGetLastError());
     return IFL_OK;

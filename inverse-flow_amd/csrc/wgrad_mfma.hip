@@ -470,8 +470,18 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
     const size_t idx = (size_t)blockIdx.x * 64 + (threadIdx.x & 63); // float4 element
     __shared__ floatx4 red[4][64];
     floatx4 s = {0.f, 0.f, 0.f, 0.f};
-    if (idx < total4)
-        for (int k = sub; k < nsplit; k += 4) s += ((const floatx4 *)partial)[(size_t)k * total4 + idx];
+    if (idx < total4) {
+        // (all loads of a batch in flight before the first add: the sum keeps its order, the latencies overlap)
+        int k = sub;
+        for (; k + 28 < nsplit; k += 32) {
+            floatx4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ((const floatx4 *)partial)[(size_t)(k + 4 * u) * total4 + idx];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < nsplit; k += 4) s += ((const floatx4 *)partial)[(size_t)k * total4 + idx];
+    }
     red[sub][threadIdx.x & 63] = s;
     __syncthreads();
     if (sub == 0 && idx < total4) {

@@ -196,9 +196,15 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
         const float *ap = a + ((size_t)b * C + 32 * bp + m) * H * W + 8 * hh;
         const float *bpz = bb + ((size_t)b * C + 32 * bq + m) * H * W + 8 * hh;
 
-        half8 Bz[KH][NKS][2]; // rolling rows of bb: [0] current, [i] i steps earlier
+        // rows of bb in a ring of four register sets, rotated by NAME (the row loop is unrolled by four): in phase P the
+        // current row is set P, the row i steps earlier set (P - i) mod 4, and the next row is converted into set
+        // (P + 1) mod 4 -- the one whose row has just left the kernel's reach.  (Rolling the VALUES cost 32-64 register
+        // moves per row.)
+        constexpr int RB = 4;
+        static_assert(KH < RB, "ring: KH rows in use + the one being converted");
+        half8 Bz[RB][NKS][2];
 #pragma unroll
-        for (int i = 0; i < KH; ++i)
+        for (int i = 0; i < RB; ++i)
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
                 const int r = r_first - sg * i;
                 if (r >= 0 && r < H) {
 #pragma unroll
-                    for (int ks = 0; ks < NKS; ++ks) split8(hv[i][ks][0], hv[i][ks][1], sb, Bz[i][ks][0], Bz[i][ks][1]);
+                    for (int ks = 0; ks < NKS; ++ks) split8(hv[i][ks][0], hv[i][ks][1], sb, Bz[(RB - i) % RB][ks][0], Bz[(RB - i) % RB][ks][1]);
                 }
             }
         }
@@ -257,11 +263,11 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
         };
         using S0 = std::integral_constant<int, 0>;
         using S1 = std::integral_constant<int, 1>;
-        half8 Au[NKS][2];
+        half8 Ab[2][NKS][2]; // a fragments of the current row (set P mod 2) and of the next one
         fetch(S0{}, 0);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            split8(ra[0][ks][0], ra[0][ks][1], sa, Au[ks][0], Au[ks][1]);
+            split8(ra[0][ks][0], ra[0][ks][1], sa, Ab[0][ks][0], Ab[0][ks][1]);
             split8(rb[0][ks][0], rb[0][ks][1], sb, Bz[0][ks][0], Bz[0][ks][1]);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -271,8 +277,13 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
 
         IFL_WSTAMP(0); // prologue
         // iteration `step`: converts set SET = (step+1) mod 2 (row step+1), reloads it with row step+3
-        auto row_step = [&](auto set_c, const int step) {
-            constexpr int SET = decltype(set_c)::value;
+        auto row_step = [&](auto ph_c, const int step) {
+            constexpr int P = decltype(ph_c)::value; // step mod 4
+            constexpr int SET = (P + 1) & 1;
+            using set_t = std::integral_constant<int, SET>;
+            auto &Au = Ab[P & 1];
+            auto &An = Ab[(P + 1) & 1];
+            auto &Bn = Bz[(P + 1) % RB];
             // heads of the next 8-column block, exchanged across the two wave halves:
             // a lane with hh=0 needs the hh=1 lane's block of the same k-step, a lane with hh=1 the
             // hh=0 lane's block of the next k-step (zero past the row end)
@@ -313,7 +324,6 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
             __builtin_amdgcn_sched_barrier(0);
             IFL_WSTAMP(1); // shifts
             // the next row's fragments
-            half8 An[NKS][2], Bn[NKS][2];
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 split8(ra[SET][ks][0], ra[SET][ks][1], sa, An[ks][0], An[ks][1]);
@@ -329,40 +339,34 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
                     for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
                         for (int i = 0; i < KH; ++i)
-                            acc[i * KW + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(As[j][ks][pr == 2 ? 1 : 0], Bz[i][ks][pr == 1 ? 1 : 0],
+                            acc[i * KW + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(As[j][ks][pr == 2 ? 1 : 0], Bz[(P - i + RB) % RB][ks][pr == 1 ? 1 : 0],
                                                                                      acc[i * KW + j], 0, 0, 0);
             // the conversion rides in the MFMAs' shadow: an MFMA holds the matrix pipe for 32 cycles
 #pragma unroll
             for (int k = 0; k < KW * NKS * 3 * KH; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, SET);
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, SET);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, P);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, P);
             }
             __builtin_amdgcn_sched_barrier(0);
             IFL_WSTAMP(3); // MFMAs + conversion of the next row
-            fetch(set_c, step + 3); // (unconditional: a branch would park the loads elsewhere)
+            fetch(set_t{}, step + 3); // (unconditional: a branch would park the loads elsewhere)
             __builtin_amdgcn_sched_barrier(0);
-            // roll the rows of bb
-#pragma unroll
-            for (int i = KH - 1; i >= 1; --i)
-#pragma unroll
-                for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-                    for (int hl = 0; hl < 2; ++hl) Bz[i][ks][hl] = Bz[i - 1][ks][hl];
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-                for (int hl = 0; hl < 2; ++hl) {
-                    Bz[0][ks][hl] = Bn[ks][hl];
-                    Au[ks][hl] = An[ks][hl];
-                }
-            IFL_WSTAMP(2); // loads + roll
+            IFL_WSTAMP(2); // loads
         };
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        using P2 = std::integral_constant<int, 2>;
+        using P3 = std::integral_constant<int, 3>;
         int step = 0;
-        for (; step + 1 < nsteps; step += 2) {
-            row_step(S1{}, step);
-            row_step(S0{}, step + 1);
+        for (; step + 3 < nsteps; step += 4) {
+            row_step(P0{}, step);
+            row_step(P1{}, step + 1);
+            row_step(P2{}, step + 2);
+            row_step(P3{}, step + 3);
         }
-        if (step < nsteps) row_step(S1{}, step);
+        if (step < nsteps) row_step(P0{}, step);
+        if (step + 1 < nsteps) row_step(P1{}, step + 1);
+        if (step + 2 < nsteps) row_step(P2{}, step + 2);
     }
     IFL_WSTAMP(4);
 

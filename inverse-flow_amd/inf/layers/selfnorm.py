@@ -92,7 +92,8 @@ class SelfNormConvFunc(torch.autograd.Function):
         weight_grad_fwd = (delta_z_xt - flip_kernel(R) * multiple) / 2.0
         input_grad = _h.conv2d_igrad(go, W, x.shape, p)
         Wx = output - bw.view(1, -1, 1, 1) if bw is not None else output
-        neg_delta_x_Wxt = _h.conv2d_wgrad((-input_grad).contiguous(), Wx.contiguous(), R.shape, p)
+        # (the weight gradient is linear in its first operand: negate the C*C*K*K result, not the activation)
+        neg_delta_x_Wxt = -_h.conv2d_wgrad(input_grad, Wx.contiguous(), R.shape, p)
         weight_grad_inv = (neg_delta_x_Wxt + flip_kernel(W) * flip_kernel(multiple)) / 2.0
         bw_grad = go.flatten(2).sum(-1).sum(0) if bw is not None else None
         return input_grad, weight_grad_fwd, bw_grad, weight_grad_inv, None, None, None, None

@@ -82,8 +82,7 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_conv_mfma(const float *__rest
                                                               int H, int pt, int pl)
 {
     using Cfg = ConvCfg<C, KH, KW, WT>;
-    constexpr int NQ = Cfg::NQ, NT = Cfg::NT, RB = Cfg::RB, PC = Cfg::PC, PP = Cfg::PP, PB = Cfg::PB, TPR = Cfg::TPR,
-                  NP = Cfg::NP;
+    constexpr int NQ = Cfg::NQ, NT = Cfg::NT, RB = Cfg::RB, PC = Cfg::PC, PP = Cfg::PP, PB = Cfg::PB, TPR = Cfg::TPR;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -208,113 +207,145 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_conv_mfma(const float *__rest
     floatx4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias) bv = floatx4{bias[c0], bias[c0 + 1], bias[c0 + 2], bias[c0 + 3]};
 
-    // fragments of one tap: [buffer][tile of the pair][k-step][hi/lo].  Small on purpose: a fragment register that
-    // the compiler has to park somewhere else (AGPR spill) right behind the inline-asm read would be copied before
-    // its data has landed.
-    half8 F[2][2][NQ][2];
-    floatx4 ahi[2], amid[2];
-    constexpr int NRD = 2 * NQ * 2; // requests of one tap
-    constexpr int NMF = 2 * NQ * 3; // MFMAs of one tap
-
-    // request number j of tap T_ of pair p, into buffer BUF
-    auto request = [&](auto buf_c, auto tap_c, int p, int j) {
-        constexpr int BUF = decltype(buf_c)::value, TAP = decltype(tap_c)::value;
-        constexpr int OFFT = ((TAP / KW) * PC + (TAP % KW)) * 16; // the tap's pixel offset
+    // "Push" form (as in the scan): a fragment of staged row ri shifted by kw columns is the B operand of the taps
+    // (kh, kw) of the output rows ri - kh, kh = 0..KH-1.  It is read from LDS once and multiplied into up to KH
+    // accumulator rows -- a third of the LDS requests of a tap-by-tap loop, and 12..36 MFMAs between a stage's
+    // requests and their use.  All RB x TPR output tiles of the band accumulate side by side.
+    //   stage S = (ri, kw) = (S / KW, S % KW); fragments [buffer][tile of the row][k-step][hi/lo], buffers alternate
+    half8 F[2][TPR][NQ][2];
+    floatx4 ahi[RB][TPR], amid[RB][TPR];
+    constexpr int NRD = TPR * NQ * 2; // requests of one stage
+    constexpr int NST = PR * KW;      // stages of a band
+    // (request / MFMA numbers are compile-time constants: with a run-time number the selection below turns into a
+    // chain of branches per MFMA as soon as the enclosing loop is too long to be unrolled)
+    auto request = [&](auto buf_c, auto st_c, auto j_c) {
+        constexpr int BUF = decltype(buf_c)::value, S = decltype(st_c)::value, j = decltype(j_c)::value;
+        constexpr int OFF = ((S / KW) * PC + (S % KW)) * 16; // the stage's pixel offset
         int c = 0;
 #pragma unroll
-        for (int T = 0; T < 2; ++T) {
-            const int t = 2 * p + T, r = t / TPR, w0 = 16 * (t % TPR);
-            const unsigned a0 = fa_lane + (r * PC + w0) * 16;
+        for (int T = 0; T < TPR; ++T) {
+            const unsigned a0 = fa_lane + (16 * T) * 16;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                // plane (q, hl, g): q and the pixel in the address register, hl and the tap in the offset field
-                if (c++ == j) lds_read_b128_o<OFFT>(F[BUF][T][q][0], a0 + q * 8 * PB);
-                if (c++ == j) lds_read_b128_o<4 * PB + OFFT>(F[BUF][T][q][1], a0 + q * 8 * PB);
+                // plane (q, hl, g): q and the tile in the address register, hl and the stage in the offset field
+                if (c++ == j) lds_read_b128_o<OFF>(F[BUF][T][q][0], a0 + q * 8 * PB);
+                if (c++ == j) lds_read_b128_o<4 * PB + OFF>(F[BUF][T][q][1], a0 + q * 8 * PB);
             }
         }
     };
-    // MFMA number k of tap TAP from buffer BUF (order: per k-step hi.hi, hi.lo of both tiles, then the lo.hi
-    // products); the pair's first tap starts its accumulators from zero
-    auto mfma = [&](auto buf_c, auto tap_c, int k) {
-        constexpr int BUF = decltype(buf_c)::value, TAP = decltype(tap_c)::value;
+    // MFMA number k of stage S from buffer BUF: per k-step the hi.hi and hi.lo products of all (row, tile) targets, then
+    // the lo.hi products (dependent MFMAs stay >= 2 apart); an output row's first product starts from zero
+    auto mfma = [&](auto buf_c, auto st_c, auto k_c) {
+        constexpr int BUF = decltype(buf_c)::value, S = decltype(st_c)::value, RI = S / KW, KWI = S % KW, k = decltype(k_c)::value;
         const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
         int c = 0;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-            for (int T = 0; T < 2; ++T)
-                if (c++ == k)
-                    ahi[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[TAP][q][0], F[BUF][T][q][0],
-                                                                    (TAP == 0 && q == 0) ? zero : ahi[T], 0, 0, 0);
+            for (int kh = 0; kh < KH; ++kh)
 #pragma unroll
-            for (int T = 0; T < 2; ++T)
-                if (c++ == k)
-                    amid[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[TAP][q][0], F[BUF][T][q][1],
-                                                                     (TAP == 0 && q == 0) ? zero : amid[T], 0, 0, 0);
+                for (int T = 0; T < TPR; ++T)
+                    if (RI - kh >= 0 && RI - kh < RB)
+                        if (c++ == k) {
+                            ahi[RI - kh][T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                A[kh * KW + KWI][q][0], F[BUF][T][q][0], (kh == 0 && KWI == 0 && q == 0) ? zero : ahi[RI - kh][T], 0, 0, 0);
+                            asm volatile("" : "+a"(ahi[RI - kh][T]));
+                        }
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+                for (int T = 0; T < TPR; ++T)
+                    if (RI - kh >= 0 && RI - kh < RB)
+                        if (c++ == k) {
+                            amid[RI - kh][T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                A[kh * KW + KWI][q][0], F[BUF][T][q][1], (kh == 0 && KWI == 0 && q == 0) ? zero : amid[RI - kh][T], 0, 0, 0);
+                            asm volatile("" : "+a"(amid[RI - kh][T]));
+                        }
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int T = 0; T < 2; ++T)
-                if (c++ == k)
-                    amid[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[TAP][q][1], F[BUF][T][q][0], amid[T], 0, 0, 0);
-    };
-    auto epilogue = [&](int p) {
+            for (int kh = 0; kh < KH; ++kh)
 #pragma unroll
-        for (int T = 0; T < 2; ++T) {
-            const int t = 2 * p + T, r = t / TPR, w0 = 16 * (t % TPR);
-            const int oh = h0 + r;
-            if (oh < H) {
+                for (int T = 0; T < TPR; ++T)
+                    if (RI - kh >= 0 && RI - kh < RB)
+                        if (c++ == k) {
+                            amid[RI - kh][T] =
+                                __builtin_amdgcn_mfma_f32_16x16x32_f16(A[kh * KW + KWI][q][1], F[BUF][T][q][0], amid[RI - kh][T], 0, 0, 0);
+                            asm volatile("" : "+a"(amid[RI - kh][T]));
+                        }
+    };
+    auto epilogue = [&](int ro) {
+        const int oh = h0 + ro;
+        if (oh < H) {
+#pragma unroll
+            for (int T = 0; T < TPR; ++T)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    outb[((size_t)(c0 + e) * H + oh) * WT + w0 + n] = ahi[T][e] + amid[T][e] * LO_INV + bv[e];
-            }
+                    outb[((size_t)(c0 + e) * H + oh) * WT + 16 * T + n] = ahi[ro][T][e] + amid[ro][T][e] * LO_INV + bv[e];
         }
     };
-    // Stage S of a block of two tile pairs starting at pair p: tap S mod NT of pair p + S / NT.  Its fragments
-    // (requested during the previous stage) have landed; it multiplies while the next tap's requests go out one per
-    // MFMA (measured: an MFMA hides one ds_read_b128, tools/issue_rate_probe.hip).  Buffers alternate with S.
-    auto block_stage = [&](auto s_c, int p) {
-        constexpr int S = decltype(s_c)::value;
-        constexpr int TAP = S % NT, SN = (S + 1) % (2 * NT), TAPN = SN % NT;
+    // Stage S: its fragments (requested during the previous stage) have landed; it multiplies while the next stage's
+    // requests go out one per MFMA (measured: an MFMA hides one ds_read_b128, tools/issue_rate_probe.hip).
+    auto stage = [&](auto st_c) {
+        constexpr int S = decltype(st_c)::value, RI = S / KW, KWI = S % KW;
         using BUF = std::integral_constant<int, S & 1>;
         using NBUF = std::integral_constant<int, 1 - (S & 1)>;
-        const int pc = p + S / NT;                           // this stage's pair
-        const int pn = S + 1 < 2 * NT ? p + (S + 1) / NT : p + 2; // the next stage's pair
-        const bool more = pn < NP;
+        using NEXT = std::integral_constant<int, (S + 1 < NST ? S + 1 : S)>;
+        constexpr int RLO = RI - (KH - 1) > 0 ? RI - (KH - 1) : 0, RHI = RI < RB - 1 ? RI : RB - 1;
+        constexpr int NMF = (RHI - RLO + 1) * TPR * NQ * 3; // (RB >= KH: every staged row has a target)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < NMF; ++k) {
-            mfma(BUF{}, std::integral_constant<int, TAP>{}, k);
-            // (MFMAs are pure: tie the results to an opaque statement, or they sink below the requests)
-            asm volatile("" : "+a"(ahi[0]), "+a"(ahi[1]), "+a"(amid[0]), "+a"(amid[1]));
+        for_seq(std::make_integer_sequence<int, (NMF > NRD ? NMF : NRD)>{}, [&](auto k_c) {
+            constexpr int k = decltype(k_c)::value;
+            // (MFMAs are pure: each ties its result to an opaque statement, or they sink below the requests)
+            if constexpr (k < NMF) mfma(BUF{}, st_c, k_c);
             __builtin_amdgcn_sched_barrier(0);
-            if (k < NRD && more) request(NBUF{}, std::integral_constant<int, TAPN>{}, pn, k);
+            if constexpr (k < NRD && S + 1 < NST) request(NBUF{}, NEXT{}, k_c);
             __builtin_amdgcn_sched_barrier(0);
-        }
-        if (TAP == NT - 1) epilogue(pc);
+        });
+        // the output row whose last contribution this was
+        if constexpr (KWI == KW - 1 && RI - (KH - 1) >= 0 && RI - (KH - 1) < RB) epilogue(RI - (KH - 1));
     };
+    static_assert(RB >= KH, "a band is at least as tall as the kernel");
 
+#ifdef IFL_STAMPS
+    unsigned long long cph[4] = {0, 0, 0, 0}, clast = __builtin_amdgcn_s_memtime();
+#define IFL_CSTAMP(k)                                                  \
+    do {                                                               \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
+        cph[k] += t_ - clast;                                          \
+        clast = t_;                                                    \
+    } while (0)
+#else
+#define IFL_CSTAMP(k) \
+    do {              \
+    } while (0)
+#endif
     fetch(band0);
     for (int band = band0; band < band1; ++band) {
         h0 = band * RB;
+        IFL_CSTAMP(3);
         const float vmax = convert(); // (waits for the band's loads)
+        IFL_CSTAMP(0); // loads landed + split + LDS writes
         // (also the barrier between staging and use)
         const int ovf = __syncthreads_or(vmax < 6.0e4f ? 0 : 1);
         if (band + 1 < band1) fetch(band + 1); // in flight while this band multiplies
+        IFL_CSTAMP(1); // barrier + issue of the next band's loads
         if (ovf) {
             band_fp32(h0);
         } else {
-#pragma unroll
-            for (int j = 0; j < NRD; ++j) request(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0, j);
-            for (int p = 0; p < NP; p += 2)
-                for_seq(std::make_integer_sequence<int, 2 * NT>{}, [&](auto s_c) { block_stage(s_c, p); });
+            for_seq(std::make_integer_sequence<int, NRD>{},
+                    [&](auto j_c) { request(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, j_c); });
+            for_seq(std::make_integer_sequence<int, NST>{}, [&](auto st_c) { stage(st_c); });
         }
+        IFL_CSTAMP(2); // multiply + stores
         __syncthreads(); // every wave is done with the staged band before the next one overwrites it
     }
 #ifdef IFL_STAMPS
     if (g_cstamps && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) g_cstamps[wv] = __builtin_amdgcn_s_memtime() - cs0;
+    if (g_cstamps && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+        for (int k = 0; k < 4; ++k) g_cstamps[4 + k] = cph[k];
 #endif
 }
 

@@ -14,3 +14,4 @@ torch.cuda.synchronize()
 t = buf.cpu()
 for wv in range(4):
     print("wave", wv, "cycles for the workgroup's bands", int(t[wv]))
+print("wave 0 phases, summed over its bands:", dict(zip(["convert (loads landed, split, LDS writes)", "barrier + next loads issued", "multiply + stores", "barrier at band end"], [int(v) for v in t[4:8]])))

@@ -36,19 +36,20 @@ template <int C, int KH, int KW, int WT> struct ConvCfg {
     static constexpr int NW = C / 16;  // waves = 16-channel output groups
     static constexpr int NQ = C / 32;  // 32-deep k-steps per tap
     static constexpr int NT = KH * KW;
-    static constexpr int RB = 4;                            // output rows per band: 52 KB of LDS at C=64, W=32 -> three
-                                                            // workgroups per CU, one stages while another multiplies
+    static constexpr int RB = 4;                            // output rows per band: 52 KB of LDS at C=64, W=32 per staging
+                                                            // buffer, 64 accumulator registers
     static constexpr int PR = RB + KH - 1, PC = WT + KW - 1; // staged rows / columns (halo included)
     static constexpr int PP = PR * PC;                      // staged pixels
     static constexpr int PB = PP * 16;                      // bytes of one plane
     static constexpr int NPL = NQ * 8;                      // planes: (k-step, hi/lo, k-group)
-    static constexpr int LDSB = NPL * PB;
+    static constexpr int LDSB = NPL * PB;                   // one staged band
+    static constexpr int LDSB2 = 2 * LDSB;                  // two: a band is staged while its predecessor may still be read
     static constexpr int THREADS = 64 * NW;
     static constexpr int TPR = WT / 16;      // 16-pixel tiles per row
     static constexpr int NP = RB * TPR / 2;  // tile pairs per band
     static constexpr int BPW = 4;            // bands per workgroup: the next band's loads fly while this one multiplies
     static_assert(WT % 16 == 0 && (RB * TPR) % 2 == 0 && NP % 2 == 0, "tiles come in pairs, pairs in pairs");
-    static_assert(LDSB <= 160 * 1024, "band staging must fit the CU's LDS");
+    static_assert(LDSB2 <= 160 * 1024, "band staging must fit the CU's LDS");
     static_assert(4 * PB + (KH * PC + KW) * 16 < 65536, "fragment offsets must fit the ds offset field");
 };
 
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_conv_mfma(const float *__rest
             for (int j = 0; j < 8; ++j) raw[u][j] = ok ? *(const floatx4 *)(src + (size_t)j * H * WT) : floatx4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    auto convert = [&]() -> float {
+    auto convert = [&](unsigned char *lds) -> float { // (lds: the buffer of the band being staged)
         float vmax = 0.f;
 #pragma unroll
         for (int u = 0; u < NIT; ++u) {
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_conv_mfma(const float *__rest
             const int hc = it % NHC, rr = (it / NHC) % PR, plane = it / (NHC * PR);
             const int cc = hc < pl ? hc : WT + hc; // columns 0..pl-1 and pl+WT..PC-1
             *(half8 *)(lds + plane * PB + (rr * PC + cc) * 16) = zero8;
+            *(half8 *)(lds + Cfg::LDSB + plane * PB + (rr * PC + cc) * 16) = zero8;
         }
     }
     // a band that leaves the fp16 range (or holds a NaN/Inf): plain fp32, straight from memory.  Rare and slow.
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_conv_mfma(const float *__rest
     // ---- multiply: tile pairs, taps double-buffered ---------------------------------------------------------
     int h0 = 0; // first output row of the band being multiplied
     const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
-    const unsigned fa_lane = ldsbase + g * PB + n * 16; // this lane's piece of pixel 0 in plane (0, hi, g)
+    unsigned fa_lane = ldsbase + g * PB + n * 16; // this lane's piece of pixel 0 in plane (0, hi, g) of the band's buffer
     const int c0 = 16 * wv + 4 * g;                    // C/D layout: lane (n, g) holds channels c0..c0+3 of pixel n
     floatx4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias) bv = floatx4{bias[c0], bias[c0 + 1], bias[c0 + 2], bias[c0 + 3]};
@@ -325,8 +327,12 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_conv_mfma(const float *__rest
     fetch(band0);
     for (int band = band0; band < band1; ++band) {
         h0 = band * RB;
+        // Staging buffers alternate: this band's conversion writes the buffer that was last read two bands ago, and every
+        // wave has passed the barrier below since -- one barrier per band.
+        const int boff = ((band - band0) & 1) * Cfg::LDSB;
+        fa_lane = ldsbase + boff + g * PB + n * 16;
         IFL_CSTAMP(3);
-        const float vmax = convert(); // (waits for the band's loads)
+        const float vmax = convert(lds + boff); // (waits for the band's loads)
         IFL_CSTAMP(0); // loads landed + split + LDS writes
         // (also the barrier between staging and use)
         const int ovf = __syncthreads_or(vmax < 6.0e4f ? 0 : 1);
@@ -340,7 +346,6 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_conv_mfma(const float *__rest
             for_seq(std::make_integer_sequence<int, NST>{}, [&](auto st_c) { stage(st_c); });
         }
         IFL_CSTAMP(2); // multiply + stores
-        __syncthreads(); // every wave is done with the staged band before the next one overwrites it
     }
 #ifdef IFL_STAMPS
     if (g_cstamps && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) g_cstamps[wv] = __builtin_amdgcn_s_memtime() - cs0;
@@ -368,7 +373,7 @@ static int launch_conv_one(const float *in, const void *apack, const float *w, c
     static bool attr_done = false; // idempotent attribute, benign race
     if (!attr_done) {
         IFL_HIP(hipFuncSetAttribute((const void *)k_conv_mfma<C, KH, KW, WT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    Cfg::LDSB));
+                                    Cfg::LDSB2));
         attr_done = true;
     }
 #ifdef IFL_STAMPS
@@ -379,7 +384,7 @@ static int launch_conv_one(const float *in, const void *apack, const float *w, c
 #endif
     const int nbands = (H + Cfg::RB - 1) / Cfg::RB;
     const dim3 grid((nbands + Cfg::BPW - 1) / Cfg::BPW, B);
-    hipLaunchKernelGGL((k_conv_mfma<C, KH, KW, WT>), grid, dim3(Cfg::THREADS), Cfg::LDSB, s, in, (const half8 *)apack, w,
+    hipLaunchKernelGGL((k_conv_mfma<C, KH, KW, WT>), grid, dim3(Cfg::THREADS), Cfg::LDSB2, s, in, (const half8 *)apack, w,
                        bias, out, H, pt, pl);
     IFL_HIP(hipGetLastError());
     return IFL_OK;

@@ -386,3 +386,48 @@ def test_split_scan_redoes_void_images_whole(H, oracle):
         _no_split(False)
     for b in range(B):
         assert rel_err(host(z_w)[b], z_o[b]) < TOL, b
+
+
+def test_split_scan_streams_and_graph_replay(H):
+    """The split scan's hand-off state is per (device, stream) and its tags are device-side generations: two streams run
+    split scans concurrently without sharing a mailbox, and a captured launch replays correctly any number of times
+    (a per-launch host argument would be frozen into the graph)."""
+    torch.manual_seed(7)
+    B, C, Hh, Ww, K = 24, 64, 32, 32, 3
+    w = torch.nn.init.dirac_(torch.empty(C, C, K, K)) + 0.02 * torch.randn(C, C, K, K)
+    w[:, -1, -1, -1] = 1.0
+    w = w.cuda()
+    xs = [torch.randn(B, C, Hh, Ww, device="cuda") for _ in range(2)]
+    _no_split(True)
+    try:
+        refs = [H.inverse(x, w) for x in xs]
+    finally:
+        _no_split(False)
+    torch.cuda.synchronize()
+    # two side streams, interleaved launches
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    for it in range(6):
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                outs[k].append(H.inverse(xs[k], w))
+    torch.cuda.synchronize()
+    for k in range(2):
+        for z in outs[k]:
+            assert torch.equal(z, refs[k])
+    # graph capture + replay on one of them (its state block exists: the launches above created it)
+    s = streams[0]
+    zg = torch.empty_like(xs[0])
+    xin = xs[0].clone()
+    with torch.cuda.stream(s):
+        H.inverse(xin, w, out=zg)  # warm-up on the capture stream
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            H.inverse(xin, w, out=zg)
+    for k in (0, 1, 0):
+        xin.copy_(xs[k])
+        zg.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(zg, refs[k]), k

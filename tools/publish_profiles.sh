@@ -8,6 +8,9 @@ cd $ROOT
 cp $SRC/bench.json profiles/r01_final_bench.json
 python tools/rocpd_summary.py $SRC/stats/stats_results.db > profiles/r01_final_rocprofv3_kernel_stats.txt
 python tools/rocpd_summary.py $SRC/pmc_fetch/fetch_results.db $SRC/pmc_write/write_results.db > profiles/r01_final_rocprofv3_pmc_hbm.txt
+if [ -f $SRC/pmc_sq/sq_results.db ]; then
+  python tools/rocpd_summary.py $SRC/pmc_sq/sq_results.db > profiles/r01_final_rocprofv3_pmc_sq.txt
+fi
 python - "$SRC" <<'PY'
 import json, re, sys
 src = sys.argv[1]

@@ -192,6 +192,31 @@ int ifl_coupling_f32(const float *x, const float *h, float *y, float *logdet, in
 int ifl_coupling_backward_f32(const float *gy, const float *g_logdet, const float *x, const float *h, float *gx, float *gh,
                               int B, int C, int H, int W, ifl_stream_t stream);
 
+/* ---- activations of the Glow step (inf/layers/activations.py) ----------------------------------------------------- */
+size_t ifl_activation_workspace_bytes(int B, int C, int n_bins); /* scratch of the calls below (n_bins = 0: SmoothLeakyRelu) */
+
+/* SmoothLeakyRelu (activations.py:37-54): y = alpha x + (1 - alpha) log(1 + e^x), logdet[b] = sum log y' (may be NULL);
+ * reverse != 0: the reference's Newton-Raphson inverse (100 iterations from x0 = y, slope clamped at 1e-2:
+ * activations.py:27-34), iterated in registers.  y may alias x. */
+int ifl_slr_f32(const float *x, float *y, float *logdet, int B, int C, int H, int W, float alpha, int reverse, void *ws,
+                size_t ws_bytes, ifl_stream_t stream);
+/* gx = gy y' + g_logdet[b] y'' / y'  (g_logdet may be NULL) */
+int ifl_slr_backward_f32(const float *gy, const float *g_logdet, const float *x, float *gx, int B, int C, int H, int W,
+                         float alpha, ifl_stream_t stream);
+
+/* SplineActivation with shared weights (activations.py:126-217): the monotone rational-quadratic spline with linear
+ * tails of inf/layers/splines/rational_quadratic.py:20-175 on knot tables cw, ch (positions, cw[0] = ch[0] =
+ * -tail_bound, cw[n_bins] = ch[n_bins] = +tail_bound) and dv (derivatives): DEVICE arrays of n_bins + 1 floats, computed
+ * from the layer's parameters by the caller (rational_quadratic.py:97-116; no host round trip).  n_bins <= 8.
+ * inverse = 0: y = spline(x), logdet[b] = sum log|dy/dx| (may be NULL);  inverse != 0: y = spline^-1(x), logdet[b] =
+ * sum log|dy/dx| of the inverse map. */
+int ifl_rqspline_f32(const float *x, const float *cw, const float *ch, const float *dv, int n_bins, float tail_bound, float *y,
+                     float *logdet, int B, int C, int H, int W, int inverse, void *ws, size_t ws_bytes, ifl_stream_t stream);
+/* backward of the forward direction: gx and g_tables = d loss / d (cw, ch, dv): DEVICE array of 3 (n_bins + 1) floats */
+int ifl_rqspline_backward_f32(const float *gy, const float *g_logdet, const float *x, const float *cw, const float *ch,
+                              const float *dv, int n_bins, float tail_bound, float *gx, float *g_tables, int B, int C, int H,
+                              int W, void *ws, size_t ws_bytes, ifl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -420,3 +420,395 @@ int ifl_coupling_backward_f32(const float *gy, const float *g_logdet, const floa
 }
 
 } // extern "C"
+
+// =====================================================================================================================
+// Activations of the Glow step (inf/layers/activations.py): SmoothLeakyRelu (the CIFAR model) and SplineActivation with
+// shared weights (the ImageNet-32 model).  The reference evaluates the spline on (B,C,H,W,n_bins) expansions of its
+// 3 n_bins - 1 parameters through some fifty eager kernels; here the knot tables (n_bins + 1 entries each, computed by
+// the host layer from the parameters with the reference's formulas) sit in registers and an element is one pass.
+// =====================================================================================================================
+namespace ifl {
+
+// ---- SmoothLeakyRelu (activations.py:37-54): y = a x + (1 - a) softplus(x), y' = a + (1 - a) sigmoid(x),
+//      logdet[b] = sum log y'; reverse by Newton-Raphson with the reference's clamp and iteration count, in registers.
+__device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(GS_T) void k_slr(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ partial,
+                                              int HW, float alpha, int reverse, int n_iter)
+{
+    __shared__ float sh[4];
+    const size_t plane = blockIdx.x;
+    const float *xp = x + plane * HW;
+    float *yp = y + plane * HW;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < HW; i += GS_T) {
+        const float v = xp[i];
+        if (!reverse) {
+            yp[i] = alpha * v + (1.f - alpha) * softplus_f(v);
+            acc += logf(alpha + (1.f - alpha) * sigmoid_f(v));
+        } else { // newton_raphson_inverse (activations.py:27-34): x <- x - (f(x) - y) / max(f'(x), 1e-2), x0 = y
+            float t = v;
+            for (int it = 0; it < n_iter; ++it) {
+                const float fp = fmaxf(alpha + (1.f - alpha) * sigmoid_f(t), 1e-2f);
+                t = t - (alpha * t + (1.f - alpha) * softplus_f(t) - v) / fp;
+            }
+            yp[i] = t;
+        }
+    }
+    if (!reverse && partial) {
+        const float s = block_sum(acc, sh);
+        if (threadIdx.x == 0) partial[plane] = s;
+    }
+}
+// gx = gy y' + g_logdet[b] y'' / y',  y'' = (1 - a) s (1 - s)
+__global__ __launch_bounds__(GS_T) void k_slr_bwd(const float *__restrict__ gy, const float *__restrict__ g_logdet,
+                                                  const float *__restrict__ x, float *__restrict__ gx, int C, int HW,
+                                                  float alpha)
+{
+    const size_t plane = blockIdx.x;
+    const float gl = g_logdet ? g_logdet[plane / C] : 0.f;
+    const float *gp = gy + plane * HW, *xp = x + plane * HW;
+    float *op = gx + plane * HW;
+    for (int i = threadIdx.x; i < HW; i += GS_T) {
+        const float s = sigmoid_f(xp[i]);
+        const float d1 = alpha + (1.f - alpha) * s, d2 = (1.f - alpha) * s * (1.f - s);
+        op[i] = gp[i] * d1 + gl * d2 / d1;
+    }
+}
+// logdet[b] = sum_c partial[b][c] (channels in order)
+__global__ void k_plane_sums(const float *__restrict__ partial, float *__restrict__ logdet, int B, int C)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += partial[(size_t)b * C + c];
+    logdet[b] = s;
+}
+
+// ---- rational-quadratic spline with linear tails (splines/rational_quadratic.py:20-175), shared knots ---------------
+// cw, ch: NB + 1 knot positions (cw[0] = ch[0] = -tail, cw[NB] = ch[NB] = +tail), dv: NB + 1 knot derivatives.
+static constexpr int RQ_MAXB = 8;
+struct RqTables {
+    float cw[RQ_MAXB + 1], ch[RQ_MAXB + 1], dv[RQ_MAXB + 1];
+};
+
+// forward-mode derivative carrier over the 7 quantities an element depends on: x, cw[k], cw[k+1], ch[k], ch[k+1],
+// dv[k], dv[k+1]
+template <int N> struct Dual {
+    float v, d[N];
+};
+template <int N> __device__ __forceinline__ Dual<N> dvar(float v, int i)
+{
+    Dual<N> r;
+    r.v = v;
+#pragma unroll
+    for (int k = 0; k < N; ++k) r.d[k] = k == i ? 1.f : 0.f;
+    return r;
+}
+template <int N> __device__ __forceinline__ Dual<N> operator+(const Dual<N> &a, const Dual<N> &b)
+{
+    Dual<N> r;
+    r.v = a.v + b.v;
+#pragma unroll
+    for (int k = 0; k < N; ++k) r.d[k] = a.d[k] + b.d[k];
+    return r;
+}
+template <int N> __device__ __forceinline__ Dual<N> operator-(const Dual<N> &a, const Dual<N> &b)
+{
+    Dual<N> r;
+    r.v = a.v - b.v;
+#pragma unroll
+    for (int k = 0; k < N; ++k) r.d[k] = a.d[k] - b.d[k];
+    return r;
+}
+template <int N> __device__ __forceinline__ Dual<N> operator*(const Dual<N> &a, const Dual<N> &b)
+{
+    Dual<N> r;
+    r.v = a.v * b.v;
+#pragma unroll
+    for (int k = 0; k < N; ++k) r.d[k] = a.d[k] * b.v + a.v * b.d[k];
+    return r;
+}
+template <int N> __device__ __forceinline__ Dual<N> operator/(const Dual<N> &a, const Dual<N> &b)
+{
+    Dual<N> r;
+    const float ib = 1.0f / b.v;
+    r.v = a.v * ib;
+#pragma unroll
+    for (int k = 0; k < N; ++k) r.d[k] = (a.d[k] - r.v * b.d[k]) * ib;
+    return r;
+}
+template <int N> __device__ __forceinline__ Dual<N> operator*(float s, const Dual<N> &a)
+{
+    Dual<N> r;
+    r.v = s * a.v;
+#pragma unroll
+    for (int k = 0; k < N; ++k) r.d[k] = s * a.d[k];
+    return r;
+}
+template <int N> __device__ __forceinline__ Dual<N> dlog(const Dual<N> &a)
+{
+    Dual<N> r;
+    const float ia = 1.0f / a.v;
+    r.v = logf(a.v);
+#pragma unroll
+    for (int k = 0; k < N; ++k) r.d[k] = a.d[k] * ia;
+    return r;
+}
+// searchsorted (rational_quadratic.py:12-17): #(knots <= v) - 1, the last knot raised by 1e-6
+template <int NB> __device__ __forceinline__ int rq_bin(const float (&knots)[RQ_MAXB + 1], float v)
+{
+    int k = -1;
+#pragma unroll
+    for (int j = 0; j <= NB; ++j) k += (v >= (j == NB ? knots[j] + 1e-6f : knots[j])) ? 1 : 0;
+    return k < 0 ? 0 : (k > NB - 1 ? NB - 1 : k);
+}
+template <int NB> __device__ __forceinline__ void rq_pick(const RqTables &t, int k, float &a, float &b, float &c, float &e,
+                                                          float &d0, float &d1)
+{
+    a = b = c = e = d0 = d1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+        if (j == k) {
+            a = t.cw[j];
+            b = t.cw[j + 1];
+            c = t.ch[j];
+            e = t.ch[j + 1];
+            d0 = t.dv[j];
+            d1 = t.dv[j + 1];
+        }
+}
+// the spline's value and log-derivative (forward direction), generic in the scalar type (float or Dual)
+template <class T> __device__ __forceinline__ void rq_eval(const T &x, const T &a, const T &b, const T &c, const T &e,
+                                                           const T &d0, const T &d1, T &y, T &lad, T (*logfn)(const T &))
+{
+    const T w = b - a, h = e - c, delta = h / w, theta = (x - a) / w;
+    const T om = (b - x) / w; // 1 - theta
+    const T t1 = theta * om;
+    const T num = h * (delta * theta * theta + d0 * t1);
+    const T den = delta + (d0 + d1 - (delta + delta)) * t1;
+    y = c + num / den;
+    const T dnum = delta * delta * (d1 * theta * theta + (delta + delta) * t1 + d0 * om * om);
+    lad = logfn(dnum) - (logfn(den) + logfn(den));
+}
+__device__ __forceinline__ float flog(const float &a) { return logf(a); }
+
+template <int NB>
+__global__ __launch_bounds__(GS_T) void k_rqspline(const float *__restrict__ x, float *__restrict__ y,
+                                                   float *__restrict__ partial, const float *__restrict__ cw,
+                                                   const float *__restrict__ ch, const float *__restrict__ dv, int HW,
+                                                   float tail, int inverse)
+{
+    __shared__ float sh[4];
+    RqTables t; // (wave-uniform loads: the tables live in scalar registers)
+#pragma unroll
+    for (int j = 0; j <= NB; ++j) {
+        t.cw[j] = cw[j];
+        t.ch[j] = ch[j];
+        t.dv[j] = dv[j];
+    }
+    const size_t plane = blockIdx.x;
+    const float *xp = x + plane * HW;
+    float *yp = y + plane * HW;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < HW; i += GS_T) {
+        const float v = xp[i];
+        float out = v, lad = 0.f;
+        if (v >= -tail && v <= tail) {
+            float a, b, c, e, d0, d1;
+            if (!inverse) {
+                rq_pick<NB>(t, rq_bin<NB>(t.cw, v), a, b, c, e, d0, d1);
+                rq_eval<float>(v, a, b, c, e, d0, d1, out, lad, flog);
+            } else { // rational_quadratic.py:132-157
+                rq_pick<NB>(t, rq_bin<NB>(t.ch, v), a, b, c, e, d0, d1);
+                const float w = b - a, h = e - c, delta = h / w, s = d0 + d1 - 2.f * delta, r = v - c;
+                const float qa = r * s + h * (delta - d0), qb = h * d0 - r * s, qc = -delta * r;
+                const float root = (2.f * qc) / (-qb - sqrtf(qb * qb - 4.f * qa * qc));
+                out = root * w + a;
+                const float t1 = root * (1.f - root), den = delta + s * t1;
+                const float dnum = delta * delta * (d1 * root * root + 2.f * delta * t1 + d0 * (1.f - root) * (1.f - root));
+                lad = -(logf(dnum) - 2.f * logf(den));
+            }
+        }
+        yp[i] = out;
+        acc += lad;
+    }
+    if (partial) {
+        const float s = block_sum(acc, sh);
+        if (threadIdx.x == 0) partial[plane] = s;
+    }
+}
+
+// backward of the forward direction: gx, and per plane the gradient with respect to the three knot tables
+// (tpart[plane][3][NB+1]); forward-mode derivatives of (y, lad) over the 7 quantities of the element's bin
+template <int NB>
+__global__ __launch_bounds__(GS_T) void k_rqspline_bwd(const float *__restrict__ gy, const float *__restrict__ g_logdet,
+                                                       const float *__restrict__ x, float *__restrict__ gx,
+                                                       float *__restrict__ tpart, const float *__restrict__ cw,
+                                                       const float *__restrict__ ch, const float *__restrict__ dv, int C,
+                                                       int HW, float tail)
+{
+    typedef Dual<7> D;
+    __shared__ float sh[4];
+    RqTables t;
+#pragma unroll
+    for (int j = 0; j <= NB; ++j) {
+        t.cw[j] = cw[j];
+        t.ch[j] = ch[j];
+        t.dv[j] = dv[j];
+    }
+    const size_t plane = blockIdx.x;
+    const float gl = g_logdet ? g_logdet[plane / C] : 0.f;
+    const float *gp = gy + plane * HW, *xp = x + plane * HW;
+    float *op = gx + plane * HW;
+    float gcw[NB + 1], gch[NB + 1], gdv[NB + 1];
+#pragma unroll
+    for (int j = 0; j <= NB; ++j) gcw[j] = gch[j] = gdv[j] = 0.f;
+    for (int i = threadIdx.x; i < HW; i += GS_T) {
+        const float v = xp[i], g = gp[i];
+        float gxi = g; // linear tails: y = x, log-derivative 0
+        if (v >= -tail && v <= tail) {
+            const int k = rq_bin<NB>(t.cw, v);
+            float a, b, c, e, d0, d1;
+            rq_pick<NB>(t, k, a, b, c, e, d0, d1);
+            D yy, ll;
+            rq_eval<D>(dvar<7>(v, 0), dvar<7>(a, 1), dvar<7>(b, 2), dvar<7>(c, 3), dvar<7>(e, 4), dvar<7>(d0, 5), dvar<7>(d1, 6), yy, ll,
+                       dlog<7>);
+            float q[7];
+#pragma unroll
+            for (int m = 0; m < 7; ++m) q[m] = g * yy.d[m] + gl * ll.d[m];
+            gxi = q[0];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const float on = j == k ? 1.f : 0.f;
+                gcw[j] += on * q[1];
+                gcw[j + 1] += on * q[2];
+                gch[j] += on * q[3];
+                gch[j + 1] += on * q[4];
+                gdv[j] += on * q[5];
+                gdv[j + 1] += on * q[6];
+            }
+        }
+        op[i] = gxi;
+    }
+#pragma unroll
+    for (int j = 0; j <= NB; ++j) {
+        const float s0 = block_sum(gcw[j], sh), s1 = block_sum(gch[j], sh), s2 = block_sum(gdv[j], sh);
+        if (threadIdx.x == 0) {
+            tpart[(plane * 3 + 0) * (NB + 1) + j] = s0;
+            tpart[(plane * 3 + 1) * (NB + 1) + j] = s1;
+            tpart[(plane * 3 + 2) * (NB + 1) + j] = s2;
+        }
+    }
+}
+// out[e] = sum over planes of tpart[plane][e] (one wave per table entry, planes strided over its lanes in order,
+// fixed shuffle tree)
+__global__ __launch_bounds__(64) void k_table_sums(const float *__restrict__ tpart, float *__restrict__ out, size_t planes, int ne)
+{
+    const int e = blockIdx.x;
+    float s = 0.f;
+    for (size_t p = threadIdx.x; p < planes; p += 64) s += tpart[p * ne + e];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (threadIdx.x == 0) out[e] = s;
+}
+
+static int rq_check(const char *who, const float *cw, const float *ch, const float *dv, int nb)
+{
+    if (nb < 1 || nb > RQ_MAXB) IFL_FAIL(IFL_EUNSUPPORTED, "%s: n_bins=%d (1..%d supported)", who, nb, RQ_MAXB);
+    if (!cw || !ch || !dv) IFL_FAIL(IFL_EINVAL, "%s: null knot table", who);
+    return IFL_OK;
+}
+
+} // namespace ifl
+
+extern "C" {
+
+size_t ifl_activation_workspace_bytes(int B, int C, int n_bins)
+{
+    const size_t planes = (size_t)(B > 0 ? B : 0) * (C > 0 ? C : 0);
+    return planes * (3 * (size_t)(n_bins > 0 ? n_bins + 1 : 1) + 1) * sizeof(float) + 256;
+}
+
+int ifl_slr_f32(const float *x, float *y, float *logdet, int B, int C, int H, int W, float alpha, int reverse, void *ws,
+                size_t ws_bytes, ifl_stream_t stream)
+{
+    clear_error();
+    if (int rc = check_dims("ifl_slr_f32", B, C, H, W)) return rc;
+    if (B == 0) return IFL_OK;
+    if (!x || !y) IFL_FAIL(IFL_EINVAL, "ifl_slr_f32: null pointer");
+    const bool want_ld = logdet && !reverse;
+    if (want_ld && (!ws || ws_bytes < ifl_activation_workspace_bytes(B, C, 0)))
+        IFL_FAIL(IFL_EWORKSPACE, "ifl_slr_f32: workspace of %zu bytes needed", ifl_activation_workspace_bytes(B, C, 0));
+    hipStream_t s = (hipStream_t)stream;
+    float *partial = want_ld ? (float *)(((uintptr_t)ws + 255) & ~(uintptr_t)255) : nullptr;
+    hipLaunchKernelGGL(k_slr, dim3((unsigned)((size_t)B * C)), dim3(GS_T), 0, s, x, y, partial, H * W, alpha, reverse, 100);
+    if (want_ld) hipLaunchKernelGGL(k_plane_sums, dim3((B + 63) / 64), dim3(64), 0, s, partial, logdet, B, C);
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+
+int ifl_slr_backward_f32(const float *gy, const float *g_logdet, const float *x, float *gx, int B, int C, int H, int W,
+                         float alpha, ifl_stream_t stream)
+{
+    clear_error();
+    if (int rc = check_dims("ifl_slr_backward_f32", B, C, H, W)) return rc;
+    if (B == 0) return IFL_OK;
+    if (!gy || !x || !gx) IFL_FAIL(IFL_EINVAL, "ifl_slr_backward_f32: null pointer");
+    hipLaunchKernelGGL(k_slr_bwd, dim3((unsigned)((size_t)B * C)), dim3(GS_T), 0, (hipStream_t)stream, gy, g_logdet, x, gx, C, H * W,
+                       alpha);
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+
+/* cw, ch, dv: DEVICE arrays of n_bins + 1 floats (the knot tables: no host round trip between the layer's parameters
+ * and the launch) */
+int ifl_rqspline_f32(const float *x, const float *cw, const float *ch, const float *dv, int n_bins, float tail_bound, float *y,
+                     float *logdet, int B, int C, int H, int W, int inverse, void *ws, size_t ws_bytes, ifl_stream_t stream)
+{
+    clear_error();
+    if (int rc = check_dims("ifl_rqspline_f32", B, C, H, W)) return rc;
+    if (int rc = rq_check("ifl_rqspline_f32", cw, ch, dv, n_bins)) return rc;
+    if (B == 0) return IFL_OK;
+    if (!x || !y) IFL_FAIL(IFL_EINVAL, "ifl_rqspline_f32: null pointer");
+    if (logdet && (!ws || ws_bytes < ifl_activation_workspace_bytes(B, C, 0)))
+        IFL_FAIL(IFL_EWORKSPACE, "ifl_rqspline_f32: workspace of %zu bytes needed", ifl_activation_workspace_bytes(B, C, 0));
+    hipStream_t s = (hipStream_t)stream;
+    float *partial = logdet ? (float *)(((uintptr_t)ws + 255) & ~(uintptr_t)255) : nullptr;
+    const dim3 grid((unsigned)((size_t)B * C));
+#define IFL_RQ(NB) \
+    case NB: hipLaunchKernelGGL(k_rqspline<NB>, grid, dim3(GS_T), 0, s, x, y, partial, cw, ch, dv, H * W, tail_bound, inverse); break;
+    switch (n_bins) { IFL_RQ(1) IFL_RQ(2) IFL_RQ(3) IFL_RQ(4) IFL_RQ(5) IFL_RQ(6) IFL_RQ(7) IFL_RQ(8) }
+#undef IFL_RQ
+    if (logdet) hipLaunchKernelGGL(k_plane_sums, dim3((B + 63) / 64), dim3(64), 0, s, partial, logdet, B, C);
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+
+/* g_tables: DEVICE array of 3 (n_bins + 1) floats: d loss / d cw, d ch, d dv */
+int ifl_rqspline_backward_f32(const float *gy, const float *g_logdet, const float *x, const float *cw, const float *ch,
+                              const float *dv, int n_bins, float tail_bound, float *gx, float *g_tables, int B, int C, int H,
+                              int W, void *ws, size_t ws_bytes, ifl_stream_t stream)
+{
+    clear_error();
+    if (int rc = check_dims("ifl_rqspline_backward_f32", B, C, H, W)) return rc;
+    if (int rc = rq_check("ifl_rqspline_backward_f32", cw, ch, dv, n_bins)) return rc;
+    if (!gy || !x || !gx || !g_tables) IFL_FAIL(IFL_EINVAL, "ifl_rqspline_backward_f32: null pointer");
+    if (!ws || ws_bytes < ifl_activation_workspace_bytes(B, C, n_bins))
+        IFL_FAIL(IFL_EWORKSPACE, "ifl_rqspline_backward_f32: workspace of %zu bytes needed", ifl_activation_workspace_bytes(B, C, n_bins));
+    hipStream_t s = (hipStream_t)stream;
+    float *tpart = (float *)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    const size_t planes = (size_t)B * C;
+    if (planes) {
+        const dim3 grid((unsigned)planes);
+#define IFL_RQ(NB) \
+    case NB: hipLaunchKernelGGL(k_rqspline_bwd<NB>, grid, dim3(GS_T), 0, s, gy, g_logdet, x, gx, tpart, cw, ch, dv, C, H * W, tail_bound); break;
+        switch (n_bins) { IFL_RQ(1) IFL_RQ(2) IFL_RQ(3) IFL_RQ(4) IFL_RQ(5) IFL_RQ(6) IFL_RQ(7) IFL_RQ(8) }
+#undef IFL_RQ
+    }
+    hipLaunchKernelGGL(k_table_sums, dim3(3 * (n_bins + 1)), dim3(64), 0, s, tpart, g_tables, planes, 3 * (n_bins + 1));
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+
+} // extern "C"

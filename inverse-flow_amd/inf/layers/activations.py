@@ -1,7 +1,236 @@
-"""Only the base class FlowSequential filters on (reference: inf/layers/activations.py);
-the activation layers themselves are outside the hot path."""
+"""Activation layers of the flow on the HIP library (reference: inf/layers/activations.py).
+
+FlowActivationLayer keeps the reference's generic surface (forward = (activation, logdet), logdet from act_prime).
+SmoothLeakyRelu and SplineActivation (shared weights) run 4-D CUDA inputs through one-pass kernels of libinvflow_hip:
+  * SmoothLeakyRelu (activations.py:37-54): value, log-derivative sum and -- for reverse -- the reference's 100 Newton
+    iterations in registers instead of 100 passes over the tensor;
+  * SplineActivation (activations.py:126-217): the reference repeats its 3 n_bins - 1 parameters to three
+    (B, C, H, W, n_bins) tensors and runs splines/rational_quadratic.py on them; here the knot tables (n_bins + 1
+    entries each) are computed from the parameters by the same formulas on tiny tensors -- autograd sees that part --
+    and the per-element spline with its derivative sums is one kernel each way (ifl_rqspline_f32 / _backward_f32).
+Anything else (other dimensionalities, CPU tensors, individual weights) takes the reference's torch expressions.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import invflow_hip as H
+
 from .flowlayer import FlowLayer
+
+_fwd32 = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_bwd32 = torch.amp.custom_bwd(device_type="cuda")
+
+MIN_BIN_WIDTH = MIN_BIN_HEIGHT = MIN_DERIVATIVE = 1e-6  # splines/rational_quadratic.py:7-9
 
 
 class FlowActivationLayer(FlowLayer):
-    pass
+    def __init__(self):
+        super().__init__()
+        self._last_logdet_value = None
+
+    def forward(self, input, context=None):
+        act = self.activation(input, context)
+        return act, self.logdet(input, context)
+
+    def act_prime(self, input, context=None):
+        raise NotImplementedError()
+
+    def logdet(self, input, context=None):
+        logderiv = torch.log(torch.abs(self.act_prime(input, context)))
+        return logderiv.flatten(start_dim=1).sum(dim=-1)
+
+    def reverse(self, input, context=None):
+        raise NotImplementedError()
+
+
+def newton_raphson_inverse(f, y, x0, context=None, n_iter=100):
+    x = x0  # activations.py:27-34
+    for _ in range(n_iter):
+        fprime = torch.clamp(f.act_prime(x, context), min=1e-2)
+        x = x - (f.activation(x, context) - y) / fprime
+    return x
+
+
+def _hip_ok(t):
+    return t.dim() == 4 and t.is_cuda and t.dtype in (torch.float32, torch.float16, torch.bfloat16)
+
+
+class _SlrFn(torch.autograd.Function):
+    @staticmethod
+    @_fwd32
+    def forward(ctx, x, alpha):
+        x = x.contiguous()
+        y, ld = H.slr(x, alpha)
+        ctx.save_for_backward(x)
+        ctx.alpha = alpha
+        return y, ld
+
+    @staticmethod
+    @_bwd32
+    def backward(ctx, gy, gld):
+        (x,) = ctx.saved_tensors
+        return H.slr_backward(gy.contiguous(), None if gld is None else gld.contiguous(), x, ctx.alpha), None
+
+
+class SmoothLeakyRelu(FlowActivationLayer):
+    def __init__(self, alpha=0.3):
+        super().__init__()
+        self.alpha = alpha
+
+    def activation(self, input, context=None):
+        alpha = self.alpha
+        stacked = torch.stack((torch.zeros_like(input), input))
+        return alpha * input + (1 - alpha) * torch.logsumexp(stacked, dim=0)
+
+    def act_prime(self, input, context=None):
+        return self.alpha + (1 - self.alpha) * torch.sigmoid(input)
+
+    def forward(self, input, context=None):
+        if _hip_ok(input):
+            return _SlrFn.apply(input, float(self.alpha))
+        return super().forward(input, context)
+
+    def reverse(self, input, context=None):
+        if _hip_ok(input) and input.dtype == torch.float32 and not torch.is_grad_enabled():
+            return H.slr(input.contiguous(), float(self.alpha), reverse=True)
+        y, x0 = input, input
+        return newton_raphson_inverse(self, y, x0, context)
+
+
+def spline_tables(unnormalized_widths, unnormalized_heights, unnormalized_derivatives, tail_bound):
+    """Knot tables of the shared-weight spline with linear tails: cumwidths, cumheights, derivatives (n_bins + 1 entries
+    each), by the formulas of splines/rational_quadratic.py:35-46,97-116 applied to the 1-D parameters."""
+    nb = unnormalized_widths.shape[-1]
+    constant = float(np.log(np.exp(1 - MIN_DERIVATIVE) - 1))
+    ud = F.pad(unnormalized_derivatives, pad=(1, 1)) + constant
+    left = bottom = -tail_bound
+    right = top = tail_bound
+
+    def knots(u, lo, hi, min_size):
+        v = F.softmax(u, dim=-1)
+        v = min_size + (1 - min_size * nb) * v
+        cum = torch.cumsum(v, dim=-1)
+        cum = F.pad(cum, pad=(1, 0), mode='constant', value=0.0)
+        cum = (hi - lo) * cum + lo
+        edge = torch.zeros_like(cum)
+        edge[0], edge[-1] = lo, hi
+        keep = torch.ones_like(cum)
+        keep[0] = keep[-1] = 0.0
+        return cum * keep + edge  # cum[0] = lo, cum[-1] = hi without an in-place write (same values, same gradients)
+
+    cw = knots(unnormalized_widths, left, right, MIN_BIN_WIDTH)
+    ch = knots(unnormalized_heights, bottom, top, MIN_BIN_HEIGHT)
+    dv = MIN_DERIVATIVE + F.softplus(ud)
+    return cw, ch, dv
+
+
+class _SplineFn(torch.autograd.Function):
+    @staticmethod
+    @_fwd32
+    def forward(ctx, x, cw, ch, dv, tail_bound):
+        x = x.contiguous()
+        y, ld = H.rqspline(x, cw, ch, dv, tail_bound)
+        ctx.save_for_backward(x, cw, ch, dv)
+        ctx.tail_bound = tail_bound
+        return y, ld
+
+    @staticmethod
+    @_bwd32
+    def backward(ctx, gy, gld):
+        x, cw, ch, dv = ctx.saved_tensors
+        gx, gcw, gch, gdv = H.rqspline_backward(gy.contiguous(), None if gld is None else gld.contiguous(), x, cw, ch, dv,
+                                                ctx.tail_bound)
+        return gx, gcw, gch, gdv, None
+
+
+class SplineActivation(FlowActivationLayer):
+    def __init__(self, input_size, n_bins=5, tail_bound=10., individual_weights=False):
+        super().__init__()
+        self.n_bins = n_bins
+        self.tail_bound = tail_bound
+        self.individual_weights = individual_weights
+        if individual_weights:
+            self.unnormalized_widths = torch.nn.Parameter(torch.randn(1, *input_size, n_bins) * 0.01)
+            self.unnormalized_heights = torch.nn.Parameter(torch.randn(1, *input_size, n_bins) * 0.01)
+            self.unnormalized_derivatives = torch.nn.Parameter(torch.randn(1, *input_size, n_bins - 1) * 0.01)
+        else:
+            self.unnormalized_widths = torch.nn.Parameter(torch.randn(n_bins) * 0.01)
+            self.unnormalized_heights = torch.nn.Parameter(torch.randn(n_bins) * 0.01)
+            self.unnormalized_derivatives = torch.nn.Parameter(torch.randn(n_bins - 1) * 0.01)
+
+    def _hip(self, input):
+        return _hip_ok(input) and not self.individual_weights and 1 <= self.n_bins <= 8
+
+    def _tables(self):
+        return spline_tables(self.unnormalized_widths, self.unnormalized_heights, self.unnormalized_derivatives,
+                             float(self.tail_bound))
+
+    def forward(self, input, context=None):
+        return self.activation_and_logdet(input, context)
+
+    def activation_and_logdet(self, input, context=None):
+        if self._hip(input):
+            cw, ch, dv = self._tables()
+            return _SplineFn.apply(input, cw, ch, dv, float(self.tail_bound))
+        return _spline_torch(self, input, inverse=False)
+
+    def reverse(self, input, context=None):
+        if self._hip(input) and input.dtype == torch.float32 and not torch.is_grad_enabled():
+            cw, ch, dv = self._tables()
+            return H.rqspline(input.contiguous(), cw, ch, dv, float(self.tail_bound), inverse=True, want_logdet=False)[0]
+        return _spline_torch(self, input, inverse=True)[0]
+
+    def logdet(self, input, context=None):
+        return self.activation_and_logdet(input, context)[1]
+
+
+def _spline_torch(layer, input, inverse):
+    """The spline on torch expressions (reference semantics, shared or individual weights): per-element tables."""
+    if layer.individual_weights:
+        uw, uh, ud = layer.unnormalized_widths, layer.unnormalized_heights, layer.unnormalized_derivatives
+        raise NotImplementedError("individual spline weights are outside the HIP path; use the reference layer")
+    cw, ch, dv = layer._tables()
+    tb = float(layer.tail_bound)
+    inside = (input >= -tb) & (input <= tb)
+    knots = ch if inverse else cw
+    edges = knots.clone()
+    edges[-1] = edges[-1] + 1e-6
+    k = (torch.sum(input[..., None] >= edges, dim=-1) - 1).clamp(0, layer.n_bins - 1)
+    a, b, c, e, d0, d1 = cw[k], cw[k + 1], ch[k], ch[k + 1], dv[k], dv[k + 1]
+    w, h = b - a, e - c
+    delta = h / w
+    if inverse:
+        r = input - c
+        s = d0 + d1 - 2 * delta
+        qa = r * s + h * (delta - d0)
+        qb = h * d0 - r * s
+        qc = -delta * r
+        root = (2 * qc) / (-qb - torch.sqrt(qb.pow(2) - 4 * qa * qc))
+        out = root * w + a
+        t1 = root * (1 - root)
+        den = delta + s * t1
+        dnum = delta.pow(2) * (d1 * root.pow(2) + 2 * delta * t1 + d0 * (1 - root).pow(2))
+        lad = -(torch.log(dnum) - 2 * torch.log(den))
+    else:
+        theta = (input - a) / w
+        t1 = theta * (1 - theta)
+        num = h * (delta * theta.pow(2) + d0 * t1)
+        den = delta + (d0 + d1 - 2 * delta) * t1
+        out = c + num / den
+        dnum = delta.pow(2) * (d1 * theta.pow(2) + 2 * delta * t1 + d0 * (1 - theta).pow(2))
+        lad = torch.log(dnum) - 2 * torch.log(den)
+    out = torch.where(inside, out, input)
+    lad = torch.where(inside, lad, torch.zeros_like(lad))
+    return out, lad.flatten(start_dim=1).sum(dim=-1)
+
+
+class Identity(FlowActivationLayer):
+    def activation(self, input, context=None):
+        return input
+
+    def act_prime(self, input, context=None):
+        return torch.ones_like(input)
+
+    def reverse(self, input, context=None):
+        return input

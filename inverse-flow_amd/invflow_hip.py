@@ -49,6 +49,11 @@ SIGNATURES = {
     "ifl_squeeze_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ifl_coupling_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ifl_coupling_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ifl_activation_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ifl_slr_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
+    "ifl_slr_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "ifl_rqspline_f32": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "ifl_rqspline_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
 }
 
 
@@ -489,3 +494,75 @@ def coupling_backward(gy, g_logdet, x, h):
                                              _stream())
     _check(rc, "ifl_coupling_backward_f32")
     return gx, gh
+
+
+# ---- activations of the Glow step (csrc/glow_step.hip) --------------------------------------------------------------
+def _act_ws(B, C, n_bins, dev):
+    nb = lib().ifl_activation_workspace_bytes(B, C, n_bins)
+    return _ws(nb, dev), nb
+
+
+def slr(x, alpha, reverse=False, want_logdet=True):
+    """SmoothLeakyRelu.forward -> (y, logdet) / .reverse -> x (inf/layers/activations.py:37-54)."""
+    B, C, H, W = _chk4(x, "input")
+    dev = x.device
+    y = torch.empty_like(x)
+    ld = torch.empty(B, dtype=torch.float32, device=dev) if (want_logdet and not reverse) else None
+    with torch.cuda.device(dev):
+        ws, nb = _act_ws(B, C, 0, dev)
+        rc = lib().ifl_slr_f32(_ptr(x), _ptr(y), _ptr(ld), B, C, H, W, float(alpha), 1 if reverse else 0, _ptr(ws), nb,
+                               _stream())
+    _check(rc, "ifl_slr_f32")
+    return y if reverse else (y, ld)
+
+
+def slr_backward(gy, g_logdet, x, alpha):
+    B, C, H, W = _chk4(x, "input")
+    _chk_tensor(gy, "grad_output")
+    gx = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = lib().ifl_slr_backward_f32(_ptr(gy), _ptr(g_logdet), _ptr(x), _ptr(gx), B, C, H, W, float(alpha), _stream())
+    _check(rc, "ifl_slr_backward_f32")
+    return gx
+
+
+def _tables(cw, ch, dv):
+    """knot tables: three contiguous fp32 device vectors of n_bins + 1 entries"""
+    ts = [t.detach().to(torch.float32).contiguous() for t in (cw, ch, dv)]
+    n = ts[0].numel()
+    if ts[1].numel() != n or ts[2].numel() != n or n < 2 or not all(t.is_cuda for t in ts):
+        raise RuntimeError("knot tables must be CUDA vectors of n_bins + 1 entries each")
+    return ts, n - 1
+
+
+def rqspline(x, cw, ch, dv, tail_bound, inverse=False, want_logdet=True):
+    """The rational-quadratic spline with linear tails (inf/layers/splines/rational_quadratic.py:20-175) on shared
+    knot tables: (y, logdet) of the forward map, or of the inverse map."""
+    B, C, H, W = _chk4(x, "input")
+    dev = x.device
+    (a, b, c), nbins = _tables(cw, ch, dv)
+    y = torch.empty_like(x)
+    ld = torch.empty(B, dtype=torch.float32, device=dev) if want_logdet else None
+    with torch.cuda.device(dev):
+        ws, nb = _act_ws(B, C, 0, dev)
+        rc = lib().ifl_rqspline_f32(_ptr(x), _ptr(a), _ptr(b), _ptr(c), nbins, float(tail_bound), _ptr(y), _ptr(ld), B, C, H, W,
+                                    1 if inverse else 0, _ptr(ws), nb, _stream())
+    _check(rc, "ifl_rqspline_f32")
+    return y, ld
+
+
+def rqspline_backward(gy, g_logdet, x, cw, ch, dv, tail_bound):
+    """(gx, g_cw, g_ch, g_dv) of the forward direction."""
+    B, C, H, W = _chk4(x, "input")
+    _chk_tensor(gy, "grad_output")
+    dev = x.device
+    (a, b, c), nbins = _tables(cw, ch, dv)
+    gx = torch.empty_like(x)
+    gt = torch.empty(3 * (nbins + 1), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws, nb = _act_ws(B, C, nbins, dev)
+        rc = lib().ifl_rqspline_backward_f32(_ptr(gy), _ptr(g_logdet), _ptr(x), _ptr(a), _ptr(b), _ptr(c), nbins, float(tail_bound), _ptr(gx),
+                                             _ptr(gt), B, C, H, W, _ptr(ws), nb, _stream())
+    _check(rc, "ifl_rqspline_backward_f32")
+    gt = gt.view(3, nbins + 1)
+    return gx, gt[0], gt[1], gt[2]

@@ -322,3 +322,86 @@ def coupling_backward(gy, g_logdet, x, h):
     gh[:, 0::2] = (g2 * x2 * e + gl) * (1.0 - th * th)
     gh[:, 1::2] = g2
     return np.concatenate([g1, g2 * e], axis=1), gh
+
+
+# ---- activations of the Glow step (inf/layers/activations.py, splines/rational_quadratic.py), float64 -----------------
+def slr_forward(x, alpha):
+    """SmoothLeakyRelu (activations.py:37-54): (alpha x + (1 - alpha) log(1 + e^x), sum log y')."""
+    x = np.asarray(x, np.float64)
+    y = alpha * x + (1 - alpha) * np.logaddexp(0.0, x)
+    d = alpha + (1 - alpha) / (1 + np.exp(-x))
+    return y, np.log(d).reshape(len(x), -1).sum(-1)
+
+
+def slr_backward(gy, g_logdet, x, alpha):
+    x = np.asarray(x, np.float64)
+    s = 1 / (1 + np.exp(-x))
+    d1 = alpha + (1 - alpha) * s
+    d2 = (1 - alpha) * s * (1 - s)
+    gl = 0.0 if g_logdet is None else np.asarray(g_logdet, np.float64).reshape(-1, 1, 1, 1)
+    return np.asarray(gy, np.float64) * d1 + gl * d2 / d1
+
+
+def slr_reverse(y, alpha, n_iter=100):
+    """newton_raphson_inverse (activations.py:27-34): x0 = y, slope clamped at 1e-2."""
+    y = np.asarray(y, np.float64)
+    x = y.copy()
+    for _ in range(n_iter):
+        fp = np.maximum(alpha + (1 - alpha) / (1 + np.exp(-x)), 1e-2)
+        x = x - (alpha * x + (1 - alpha) * np.logaddexp(0.0, x) - y) / fp
+    return x
+
+
+def spline_tables(uw, uh, ud, tail_bound, min_size=1e-6):
+    """Knot tables (cumwidths, cumheights, derivatives) of the shared-weight spline with linear tails
+    (rational_quadratic.py:35-46,97-116)."""
+    uw, uh, ud = (np.asarray(a, np.float64) for a in (uw, uh, ud))
+    nb = len(uw)
+    const = np.log(np.exp(1 - min_size) - 1)
+    udp = np.pad(ud, (1, 1)) + const
+
+    def knots(u):
+        v = np.exp(u - u.max())
+        v = v / v.sum()
+        v = min_size + (1 - min_size * nb) * v
+        cum = np.concatenate([[0.0], np.cumsum(v)]) * 2 * tail_bound - tail_bound
+        cum[0], cum[-1] = -tail_bound, tail_bound
+        return cum
+
+    return knots(uw), knots(uh), min_size + np.logaddexp(0.0, udp)
+
+
+def rqspline(x, cw, ch, dv, tail_bound, inverse=False):
+    """Elementwise spline / inverse spline and its log-derivative (rational_quadratic.py:20-175); returns (y, logabsdet)."""
+    x = np.asarray(x, np.float64)
+    cw, ch, dv = (np.asarray(a, np.float64) for a in (cw, ch, dv))
+    nb = len(cw) - 1
+    inside = (x >= -tail_bound) & (x <= tail_bound)
+    edges = (ch if inverse else cw).copy()
+    edges[-1] += 1e-6
+    k = np.clip((x[..., None] >= edges).sum(-1) - 1, 0, nb - 1)
+    a, b, c, e, d0, d1 = cw[k], cw[k + 1], ch[k], ch[k + 1], dv[k], dv[k + 1]
+    w, h = b - a, e - c
+    delta = h / w
+    with np.errstate(all="ignore"):
+        if inverse:
+            r = x - c
+            s = d0 + d1 - 2 * delta
+            qa = r * s + h * (delta - d0)
+            qb = h * d0 - r * s
+            qc = -delta * r
+            root = (2 * qc) / (-qb - np.sqrt(qb ** 2 - 4 * qa * qc))
+            out = root * w + a
+            t1 = root * (1 - root)
+            den = delta + s * t1
+            dnum = delta ** 2 * (d1 * root ** 2 + 2 * delta * t1 + d0 * (1 - root) ** 2)
+            lad = -(np.log(dnum) - 2 * np.log(den))
+        else:
+            th = (x - a) / w
+            t1 = th * (1 - th)
+            num = h * (delta * th ** 2 + d0 * t1)
+            den = delta + (d0 + d1 - 2 * delta) * t1
+            out = c + num / den
+            dnum = delta ** 2 * (d1 * th ** 2 + 2 * delta * t1 + d0 * (1 - th) ** 2)
+            lad = np.log(dnum) - 2 * np.log(den)
+    return np.where(inside, out, x), np.where(inside, lad, 0.0)

@@ -77,6 +77,41 @@ def coupling_case(name, B, C, H, W, width, seed):
              gh=n(h.grad), x_rev=n(xr), width=np.int32(width), **sd)
 
 
+# ---- activations (appended: SmoothLeakyRelu, SplineActivation with shared weights) ------------------------------------
+def activation_cases():
+    from inf.layers.activations import SmoothLeakyRelu, SplineActivation
+
+    def run(name, layer, x, extra):
+        x = x.clone().requires_grad_(True)
+        y, ld = layer(x)
+        g = torch.Generator().manual_seed(99)
+        gy = torch.randn(x.shape, generator=g)
+        gld = torch.randn(x.shape[0], generator=g)
+        (y * gy).sum().add((ld * gld).sum()).backward()
+        with torch.no_grad():
+            xr = layer.reverse(y.detach())
+        d = dict(x=n(x), y=n(y), logdet=n(ld), gy=n(gy), gld=n(gld), gx=n(x.grad), x_rev=n(xr))
+        for k, p in layer.named_parameters():
+            d["p_" + k] = n(p)
+            d["g_" + k] = n(p.grad)
+        d.update(extra)
+        np.savez(os.path.join(HERE, name), **d)
+
+    g = torch.Generator().manual_seed(11)
+    run("slr_b3c4_6x5.npz", SmoothLeakyRelu(0.3), torch.randn(3, 4, 6, 5, generator=g) * 3, dict(alpha=np.float32(0.3)))
+    run("slr_b2c6_8x8_a01.npz", SmoothLeakyRelu(0.1), torch.randn(2, 6, 8, 8, generator=g) * 2, dict(alpha=np.float32(0.1)))
+    for name, shape, nb, tb, scale in [("spline_b3c4_6x5_n5.npz", (3, 4, 6, 5), 5, 10.0, 6.0),
+                                       ("spline_b2c6_8x8_n5_tb3.npz", (2, 6, 8, 8), 5, 3.0, 2.5),
+                                       ("spline_b2c3_4x4_n8.npz", (2, 3, 4, 4), 8, 5.0, 3.0)]:
+        layer = SplineActivation(shape[1:], n_bins=nb, tail_bound=tb)
+        with torch.no_grad():
+            for p in layer.parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * 0.8)
+        x = torch.randn(shape, generator=g) * scale  # (some elements beyond the tail bound: the linear tails)
+        x[0, 0, 0, 0], x[0, 0, 0, 1] = tb, -tb       # the interval's end points are inside
+        run(name, layer, x, dict(n_bins=np.int32(nb), tail_bound=np.float32(tb)))
+
+
 if __name__ == "__main__":
     actnorm_case("actnorm_b3c6_8x8.npz", 3, 6, 8, 8, 1, False)
     actnorm_case("actnorm_b4c5_7x5_datainit.npz", 4, 5, 7, 5, 2, True)
@@ -86,4 +121,5 @@ if __name__ == "__main__":
     coupling_case("coupling_b2c8_6x6_w16.npz", 2, 8, 6, 6, 16, 6)
     coupling_case("coupling_b3c12_8x8_w24.npz", 3, 12, 8, 8, 24, 7)
     coupling_case("coupling_b2c6_5x7_w8.npz", 2, 6, 5, 7, 8, 8)
+    activation_cases()
     print("wrote glow-step fixtures to", HERE)

@@ -45,3 +45,33 @@ def test_coupling(oracle, path):
     # the direct part of dL/dx: the second half of the channels receives nothing through the net
     ch = g["x"].shape[1] // 2
     assert rel_err(gx[:, ch:], g["gx_total"][:, ch:]) < 1e-5
+
+
+@pytest.mark.parametrize("path", golden_files("slr_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_slr(oracle, path):
+    g = load_golden(path)
+    a = float(g["alpha"])
+    y, ld = oracle.slr_forward(g["x"], a)
+    assert rel_err(y, g["y"]) < TOL and rel_err(ld, g["logdet"]) < 1e-5
+    assert rel_err(oracle.slr_backward(g["gy"], g["gld"], g["x"], a), g["gx"]) < 1e-5
+    assert rel_err(oracle.slr_reverse(g["y"], a), g["x_rev"]) < 1e-5
+
+
+@pytest.mark.parametrize("path", golden_files("spline_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_spline(oracle, path):
+    g = load_golden(path)
+    tb = float(g["tail_bound"])
+    cw, ch, dv = oracle.spline_tables(g["p_unnormalized_widths"], g["p_unnormalized_heights"],
+                                      g["p_unnormalized_derivatives"], tb)
+    y, lad = oracle.rqspline(g["x"], cw, ch, dv, tb)
+    assert rel_err(y, g["y"]) < 1e-5 and rel_err(lad.reshape(len(y), -1).sum(-1), g["logdet"]) < 1e-4
+    xr, _ = oracle.rqspline(g["y"], cw, ch, dv, tb, inverse=True)
+    assert rel_err(xr, g["x_rev"]) < 1e-5 and rel_err(xr, g["x"]) < 1e-5
+    # the input gradient by central differences of the oracle's own forward (fp64)
+    eps = 1e-6
+    gl = g["gld"].astype(np.float64).reshape(-1, 1, 1, 1)
+    yp, lp = oracle.rqspline(g["x"].astype(np.float64) + eps, cw, ch, dv, tb)
+    ym, lm = oracle.rqspline(g["x"].astype(np.float64) - eps, cw, ch, dv, tb)
+    gx = g["gy"] * (yp - ym) / (2 * eps) + gl * (lp - lm) / (2 * eps)
+    knot = np.min(np.abs(g["x"][..., None] - cw), axis=-1) < 1e-4  # (the difference quotient straddles a knot there)
+    assert rel_err(np.where(knot, 0, gx), np.where(knot, 0, g["gx"])) < 1e-4

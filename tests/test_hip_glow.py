@@ -197,3 +197,88 @@ def test_full_size_round_trips(H):
     assert float((H.coupling(z, h, reverse=True) - x).abs().max()) < 2e-5
     ref = (2 * torch.tanh(h[:, ::2].double() / 2)).flatten(1).sum(-1)
     assert float(((zl.double() - ref).abs() / ref.abs().clamp_min(1.0)).max()) < 1e-5
+
+
+# ---- activations (SmoothLeakyRelu, SplineActivation with shared weights) ---------------------------------------------
+@pytest.mark.parametrize("path", golden_files("slr_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_golden_slr(H, path):
+    from inf.layers.activations import SmoothLeakyRelu
+    g = load_golden(path)
+    a = float(g["alpha"])
+    y, ld = H.slr(dev(g["x"]), a)
+    assert rel_err(host(y), g["y"]) < TOL and rel_err(host(ld), g["logdet"]) < TOL
+    assert rel_err(host(H.slr(dev(g["y"]), a, reverse=True)), g["x_rev"]) < TOL
+    assert rel_err(host(H.slr_backward(dev(g["gy"]), dev(g["gld"]), dev(g["x"]), a)), g["gx"]) < TOL
+    layer = SmoothLeakyRelu(a)
+    x = dev(g["x"]).requires_grad_(True)
+    yl, ll = layer(x)
+    ((yl * dev(g["gy"])).sum() + (ll * dev(g["gld"])).sum()).backward()
+    assert rel_err(host(yl), g["y"]) < TOL and rel_err(host(x.grad), g["gx"]) < TOL
+    with torch.no_grad():
+        assert rel_err(host(layer.reverse(yl.detach())), g["x_rev"]) < TOL
+
+
+@pytest.mark.parametrize("path", golden_files("spline_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_golden_spline(H, oracle, path):
+    """the reference layer's parameters loaded as they are: outputs, log-det, reverse, the input gradient and the
+    gradients of the three parameter vectors (through the knot tables) against the reference's autograd"""
+    from inf.layers.activations import SplineActivation
+    g = load_golden(path)
+    nb, tb = int(g["n_bins"]), float(g["tail_bound"])
+    layer = SplineActivation(g["x"].shape[1:], n_bins=nb, tail_bound=tb)
+    layer.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("p_")})
+    layer = layer.cuda()
+    x = dev(g["x"]).requires_grad_(True)
+    y, ld = layer(x)
+    assert rel_err(host(y), g["y"]) < TOL and rel_err(host(ld), g["logdet"]) < 2e-5
+    ((y * dev(g["gy"])).sum() + (ld * dev(g["gld"])).sum()).backward()
+    assert rel_err(host(x.grad), g["gx"]) < 2e-5
+    for k, p in layer.named_parameters():
+        assert rel_err(host(p.grad), g["g_" + k]) < 1e-4, k
+    with torch.no_grad():
+        xr = layer.reverse(y.detach())
+    assert rel_err(host(xr), g["x_rev"]) < TOL and rel_err(host(xr), g["x"]) < TOL
+    # the C-ABI ops against the oracle's tables and values
+    cw, ch, dv = oracle.spline_tables(g["p_unnormalized_widths"], g["p_unnormalized_heights"], g["p_unnormalized_derivatives"], tb)
+    y2, ld2 = H.rqspline(dev(g["x"]), dev(cw), dev(ch), dev(dv), tb)
+    y_o, lad_o = oracle.rqspline(g["x"], cw, ch, dv, tb)
+    assert rel_err(host(y2), y_o) < TOL and rel_err(host(ld2), lad_o.reshape(len(y_o), -1).sum(-1)) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(4, 6, 7, 5), (16, 64, 32, 32), (3, 12, 16, 16)], ids=lambda s: "x".join(map(str, s)))
+def test_activations_against_oracle(H, oracle, shape):
+    rng = np.random.default_rng(sum(shape))
+    x = (rng.standard_normal(shape) * 4).astype(np.float32)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    gld = rng.standard_normal(shape[0]).astype(np.float32)
+    y, ld = H.slr(dev(x), 0.3)
+    y_o, ld_o = oracle.slr_forward(x, 0.3)
+    assert rel_err(host(y), y_o) < TOL and rel_err(host(ld), ld_o) < TOL
+    assert rel_err(host(H.slr(y, 0.3, reverse=True)), x) < TOL
+    assert rel_err(host(H.slr_backward(dev(gy), dev(gld), dev(x), 0.3)), oracle.slr_backward(gy, gld, x, 0.3)) < TOL
+    uw, uh, ud = rng.standard_normal(5), rng.standard_normal(5), rng.standard_normal(4)
+    cw, ch, dv = oracle.spline_tables(uw, uh, ud, 6.0)
+    s, sl = H.rqspline(dev(x), dev(cw), dev(ch), dev(dv), 6.0)
+    s_o, lad_o = oracle.rqspline(x, cw, ch, dv, 6.0)
+    assert rel_err(host(s), s_o) < TOL and rel_err(host(sl), lad_o.reshape(shape[0], -1).sum(-1)) < 2e-5
+    back, _ = H.rqspline(s, dev(cw), dev(ch), dev(dv), 6.0, inverse=True)
+    assert rel_err(host(back), x) < 2e-5
+    # gradients against autograd through this package's torch expressions of the same spline in float64 on the CPU
+    from inf.layers.activations import SplineActivation, _spline_torch
+    ref = SplineActivation(shape[1:], n_bins=5, tail_bound=6.0).double()
+    with torch.no_grad():
+        ref.unnormalized_widths.copy_(torch.from_numpy(uw)); ref.unnormalized_heights.copy_(torch.from_numpy(uh))
+        ref.unnormalized_derivatives.copy_(torch.from_numpy(ud))
+    xc = torch.from_numpy(x).double().requires_grad_(True)
+    yc, lc = _spline_torch(ref, xc, inverse=False)
+    ((yc * torch.from_numpy(gy).double()).sum() + (lc * torch.from_numpy(gld).double()).sum()).backward()
+    layer = SplineActivation(shape[1:], n_bins=5, tail_bound=6.0)
+    layer.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    layer = layer.cuda()
+    xg = dev(x).requires_grad_(True)
+    yg, lg = layer(xg)
+    ((yg * dev(gy)).sum() + (lg * dev(gld)).sum()).backward()
+    # (fp32 derivative arithmetic against a float64 truth: the log-derivative terms divide by small differences)
+    assert rel_err(host(xg.grad), xc.grad.numpy()) < 5e-5
+    for (k, p), (_, q) in zip(layer.named_parameters(), ref.named_parameters()):
+        assert rel_err(host(p.grad), q.grad.numpy()) < 1e-4, k

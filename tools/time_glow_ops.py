@@ -57,3 +57,30 @@ for name, fn, nbytes, eager in rows:
     if eager is not None:
         line += "   eager torch: %8.1f us" % timeit(eager)
     print(line)
+
+# ---- activations --------------------------------------------------------------------------------------------------
+import numpy as np
+from inf.layers.activations import SplineActivation, SmoothLeakyRelu, spline_tables
+sp = SplineActivation((C, HH, WW)).cuda()
+cw, ch, dv = [t.detach() for t in spline_tables(sp.unnormalized_widths, sp.unnormalized_heights, sp.unnormalized_derivatives, 10.0)]
+xs = x * 3
+
+
+def eager_slr():
+    return 0.3 * xs + 0.7 * torch.logsumexp(torch.stack((torch.zeros_like(xs), xs)), dim=0), torch.log(0.3 + 0.7 * torch.sigmoid(xs)).flatten(1).sum(-1)
+
+
+rows = [
+    ("slr forward", lambda: H.slr(xs, 0.3), 2 * N, eager_slr),
+    ("slr backward", lambda: H.slr_backward(gy, gld, xs, 0.3), 3 * N, None),
+    ("slr reverse (100 Newton its)", lambda: H.slr(xs, 0.3, reverse=True), 2 * N, None),
+    ("spline forward", lambda: H.rqspline(xs, cw, ch, dv, 10.0), 2 * N, None),
+    ("spline backward", lambda: H.rqspline_backward(gy, gld, xs, cw, ch, dv, 10.0), 3 * N, None),
+    ("spline inverse", lambda: H.rqspline(xs, cw, ch, dv, 10.0, inverse=True), 2 * N, None),
+]
+for name, fn, nbytes, eager in rows:
+    us = timeit(fn)
+    line = "%-30s %8.1f us  %6.2f TB/s (%.0f MB algorithmic)" % (name, us, nbytes / us / 1e6, nbytes / 1e6)
+    if eager is not None:
+        line += "   eager torch: %8.1f us" % timeit(eager)
+    print(line)

@@ -250,3 +250,69 @@ def test_layers_inside_autocast(H):
     assert torch.equal(out_b, ref_b)
     ref_u2, _ = unit(x.to(torch.bfloat16).float())
     assert torch.equal(out_u, ref_u2)
+
+
+def test_mini_glow_stack_end_to_end():
+    """A small Glow level built like inf/if_multiGPU_imagenet32.py / if_glow_cifar.py (Squeeze, then blocks of ActNorm,
+    inverse-flow layer, activation, Coupling) from this package's layers in a FlowSequential: every layer on the HIP
+    library.  Checks: reverse(forward(x)) == x; the log-likelihood's directional derivative along a random direction
+    of ALL parameters matches a central difference of the model's own forward; the input gradient likewise."""
+    from inf.layers.actnorm import ActNorm
+    from inf.layers.activations import SmoothLeakyRelu, SplineActivation
+    from inf.layers.coupling import Coupling
+    from inf.layers.flowsequential import FlowSequential
+    from inf.layers.inv_conv import inv_flow_with_pad
+    from inf.layers.squeeze import Squeeze
+    from inf.train.losses import NegativeGaussianLoss
+    torch.manual_seed(3)
+    B, C, Hh, Ww = 4, 3, 8, 8
+    size = (4 * C, Hh // 2, Ww // 2)
+    layers = [Squeeze()]
+    for k, order in enumerate(["TL", "BR"]):
+        layers += [ActNorm(size[0]), inv_flow_with_pad(size[0], size[0], (3, 3), order=order),
+                   SplineActivation(size, n_bins=5, tail_bound=4.0) if k == 0 else SmoothLeakyRelu(0.3),
+                   Coupling(size, width=16)]
+    model = FlowSequential(NegativeGaussianLoss(size=size), *layers).cuda()
+    x = torch.randn(B, C, Hh, Ww, device="cuda")
+    with torch.no_grad():
+        model(x)  # data-dependent ActNorm initialisation
+        for m in model.modules():  # give the zero-initialised coupling heads something to say
+            if isinstance(m, Coupling):
+                for p in m.net.parameters():
+                    p.add_(0.05 * torch.randn_like(p))
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def nll(inp):
+        z, lp = model(inp)
+        return -(lp.sum() / B), z
+
+    xg = x.clone().requires_grad_(True)
+    loss, z = nll(xg)
+    loss.backward()
+    assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
+    # reverse of the forward
+    with torch.no_grad():
+        h = z.detach()
+        for m in reversed(list(model.sequence_modules)):
+            h = m.reverse(h)
+        assert float((h - x).abs().max()) < 2e-4
+    # directional derivatives, one parameter tensor (and the input) at a time, against central differences of the model's
+    # own forward in float32 (eps 5e-4: at 2e-3 the inverse-conv weights are already outside their linear range and the
+    # conditioners cross ReLU kinks; all tensors at once do too)
+    eps = 5e-4
+    named = [(n_, p) for n_, p in model.named_parameters() if p.requires_grad] + [("input", None)]
+    for name, p in named:
+        d = torch.randn_like(x if p is None else p)
+        with torch.no_grad():
+            if p is None:
+                analytic = float((xg.grad * d).sum())
+                lp_, lm_ = nll(x + eps * d)[0], nll(x - eps * d)[0]
+            else:
+                analytic = float((p.grad * d).sum())
+                p.add_(eps * d)
+                lp_ = nll(x)[0]
+                p.sub_(2 * eps * d)
+                lm_ = nll(x)[0]
+                p.add_(eps * d)
+        numeric = float(lp_ - lm_) / (2 * eps)
+        assert abs(analytic - numeric) < 3e-2 * abs(numeric) + 0.3, (name, analytic, numeric)

@@ -187,13 +187,22 @@ def main():
                 traffic_src = "profiles/r01_final_scan_hbm_counters.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
         except (OSError, KeyError, ValueError):
             pass
+        # matrix-pipe busy fraction of the dominant kernel, same provenance (the SQ pass of tools/profile_round.sh)
+        mfma_busy = None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_final_sq_counters.json")) as f:
+                sq = json.load(f)
+            if dom == "scan" and world == 1:
+                mfma_busy = sq["mfma_busy_frac"]
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = {
             # the path is a dense CxC contraction (166 flop/B): MFMA-bound.  achieved = ALGORITHMIC flops
             #  / measured launch time; the kernels issue 3 f16 MFMAs per algorithmic product
             # (split fp16, fp32 accumulate), so the peak is the dense f16 MFMA peak.
             "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-            "algorithmic_bytes": nbytes,
+            "algorithmic_bytes": nbytes, "mfma_busy_frac": mfma_busy,
             "issued_tflops": 3.0 * achieved, "frac_issued": 3.0 * achieved / MFMA_F16_PEAK_TFLOPS,
             "frac_vs_f32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS,
             "avg_launch_us": avg_s * 1e6, "launches": n,

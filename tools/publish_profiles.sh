@@ -28,4 +28,16 @@ json.dump({
     "correction_note": "MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half the bytes of 16-B-per-lane reads; WRITE_SIZE is exact for 16-B-per-lane stores",
 }, open("profiles/r01_final_scan_hbm_counters.json", "w"), indent=2)
 PY
+python - <<'PY'
+import json, os, re
+p = "profiles/r01_final_rocprofv3_pmc_sq.txt"
+if os.path.exists(p):
+    txt = open(p).read()
+    m = re.search(r"k_scan_(?:split|mfma)\S*\s+.*?SQ_BUSY_CYCLES=([0-9.]+).*?SQ_VALU_MFMA_BUSY_CYCLES=([0-9.]+)", txt)
+    if m:
+        busy, mfma = float(m.group(1)), float(m.group(2))
+        json.dump({"kernel": "scan", "source": p + " (rocprofv3 --pmc, SQ pass; counters per shader engine = 32 SIMDs)",
+                   "sq_busy_cycles": busy, "sq_valu_mfma_busy_cycles": mfma, "mfma_busy_frac": mfma / (32.0 * busy)},
+                  open("profiles/r01_final_sq_counters.json", "w"), indent=2)
+PY
 ls -la profiles/

@@ -133,6 +133,17 @@ int ifl_unit_backward_f32(const float *gout, const float *const z[4], const floa
                           size_t ws_bytes, void *const carry[4], ifl_stream_t stream);
 
 /*
+ * Optional persistent state of the split scan (two workgroups per image with an in-launch hand-off: used when
+ * 16 < H <= 32 and 2 B <= the number of compute units).  The library never allocates: the caller provides ONE block of
+ * ifl_scan_state_bytes() per (device, stream), 256-byte aligned, ZERO-FILLED once before it is registered, and keeps it
+ * alive and untouched while registered (it holds the hand-off mailbox and per-image launch generations, which advance
+ * on the device: valid under graph replay).  Without a registered block every scan uses the one-workgroup-per-image
+ * kernel; results are bit-identical either way.  state = NULL unregisters the stream's block.
+ */
+size_t ifl_scan_state_bytes(void);
+int ifl_scan_state_register(void *state, size_t bytes, ifl_stream_t stream);
+
+/*
  * Weight gradient from a precomputed dx:  dw = -(sum dx (x) shifted z) * mask.
  * Second half of inv_conv_with_bp.dw (inv_conv_with_bp_general.cpp:99-112).
  */

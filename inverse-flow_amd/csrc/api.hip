@@ -263,6 +263,14 @@ size_t ifl_workspace_bytes(int op, int B, int C, int H, int W, int KH, int KW, u
     }
 }
 
+size_t ifl_scan_state_bytes(void) { return scan_state_bytes(); }
+
+int ifl_scan_state_register(void *state, size_t bytes, ifl_stream_t stream)
+{
+    clear_error();
+    return scan_state_register(state, bytes, (hipStream_t)stream);
+}
+
 size_t ifl_carry_bytes(int C, int KH, int KW)
 {
     if (C < 1 || KH < 1 || KW < 1) return 0;

@@ -90,11 +90,13 @@ struct FoldJobs {
 int launch_foldpack_jobs(const FoldJobs &jobs, int njobs, int ndir, hipStream_t s);
 // Split scan (H > 16 and at most half as many images as compute units): an image's two row tiles run on two
 // workgroups, the upper one handing the lower its last two rows of every diagonal through a mailbox.  The state
-// is owned by the library (one zero-initialised block per device and stream, see split_state()).
+// is a caller-owned zero-initialised block per device and stream (ifl_scan_state_register).
 struct SplitState {
     unsigned long long *mbox; // [image][80 steps][wave][hi, lo][8 lanes] 16-byte {value, tag, value, tag} granule pairs
     unsigned *gen;            // [image] launch generation: this launch's tag is gen + 1, the lower half advances it
 };
+size_t scan_state_bytes();
+int scan_state_register(void *state, size_t bytes, hipStream_t s); // (state = NULL: forget this stream's block)
 // amax: optional device word that receives max|z| (atomicMax of float bits; must be cleared beforehand)
 int launch_scan_mfma(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, int *flags,
                      const float *wf32, unsigned *amax, hipStream_t s);

@@ -1271,7 +1271,8 @@ int launch_foldpack_mfma(const float *w, void *out0, float *wf0, void *out1, flo
     return launch_foldpack_jobs(jobs, 1, ndir, s);
 }
 
-// ---- split-scan state: one block per (device, stream), allocated and zeroed on first use, never freed -----------
+// ---- split-scan state: a caller-owned, zero-initialised block per (device, stream), registered with
+//      ifl_scan_state_register (the library never allocates: without a registered block the whole-image kernel runs).
 // Layout: [generation per image, 128 words] [mailbox: 128 images x 80 steps x 4 waves x 256 B; the last step = verdict].
 // Tags are per-image launch generations, so the mailbox needs no cleaning between launches; generations advance on
 // the device (the lower half's last act), which keeps the scheme valid under graph replay.
@@ -1285,10 +1286,29 @@ struct SplitBlock {
     char *ptr;
 };
 std::mutex g_split_mu;
-std::vector<SplitBlock> g_split_blocks;
+std::vector<SplitBlock> g_split_blocks; // (pointers to caller-owned memory, nothing else)
 } // namespace
 
-// the block of this device and stream, or nullptr when it cannot be had right now (stream capture in progress)
+size_t scan_state_bytes() { return SPLIT_BYTES; }
+
+int scan_state_register(void *state, size_t bytes, hipStream_t s)
+{
+    int dev = 0;
+    IFL_HIP(hipGetDevice(&dev));
+    if (state && bytes < SPLIT_BYTES) IFL_FAIL(IFL_EWORKSPACE, "ifl_scan_state_register: %zu bytes needed, %zu given", SPLIT_BYTES, bytes);
+    if (state && ((uintptr_t)state & 255)) IFL_FAIL(IFL_EINVAL, "ifl_scan_state_register: the block must be 256-byte aligned");
+    std::lock_guard<std::mutex> lock(g_split_mu);
+    for (size_t i = 0; i < g_split_blocks.size(); ++i)
+        if (g_split_blocks[i].dev == dev && g_split_blocks[i].stream == s) {
+            if (state) g_split_blocks[i].ptr = (char *)state;
+            else g_split_blocks.erase(g_split_blocks.begin() + (long)i);
+            return IFL_OK;
+        }
+    if (state) g_split_blocks.push_back(SplitBlock{dev, s, (char *)state});
+    return IFL_OK;
+}
+
+// the block registered for this device and stream, or nullptr
 static char *split_state(hipStream_t s)
 {
     int dev = 0;
@@ -1296,16 +1316,7 @@ static char *split_state(hipStream_t s)
     std::lock_guard<std::mutex> lock(g_split_mu);
     for (const SplitBlock &e : g_split_blocks)
         if (e.dev == dev && e.stream == s) return e.ptr;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
-    char *ptr = nullptr;
-    if (hipMalloc((void **)&ptr, SPLIT_BYTES) != hipSuccess) return nullptr;
-    if (hipMemset(ptr, 0, SPLIT_BYTES) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-        (void)hipFree(ptr);
-        return nullptr;
-    }
-    g_split_blocks.push_back(SplitBlock{dev, s, ptr});
-    return ptr;
+    return nullptr;
 }
 
 static int device_cus()

@@ -35,6 +35,8 @@ SIGNATURES = {
     "ifl_unit_inverse_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp]),
     "ifl_unit_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp]),
     "ifl_carry_bytes": (_sz, [_i, _i, _i]),
+    "ifl_scan_state_bytes": (_sz, []),
+    "ifl_scan_state_register": (_i, [_vp, _sz, _vp]),
     "ifl_forward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "ifl_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp]),
     "ifl_dw_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
@@ -144,6 +146,29 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+# Persistent state of the split scan (include/invflow.h, ifl_scan_state_register): the library never allocates, so
+# this host layer owns one zero-filled block per (device, stream) and registers it on the stream's first scan.
+_scan_states = {}
+
+
+def _ensure_scan_state(dev):
+    """Register the split-scan block of the current stream of `dev` (no-op after the first call; skipped while the
+    stream is being captured: the whole-image kernel is used then unless the block exists already)."""
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), stream)
+    if key in _scan_states:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return
+    L = lib()
+    nb = int(L.ifl_scan_state_bytes())
+    with torch.cuda.device(dev):
+        st = torch.zeros(nb, dtype=torch.uint8, device=dev)
+        torch.cuda.current_stream(dev).synchronize()  # (the zero fill is complete before any launch can see the block)
+        _check(L.ifl_scan_state_register(_ptr(st), nb, stream), "ifl_scan_state_register")
+    _scan_states[key] = st
+
+
 def new_carry(w):
     """Buffer for the forward -> backward side channel of one step (see ifl_carry_bytes in invflow.h)."""
     C, _, KH, KW = w.shape
@@ -166,6 +191,7 @@ def inverse(x, w, order="TL", flags=0, out=None, carry=None):
     dev = _same_device(x, w, out)
     L = lib()
     with torch.cuda.device(dev):
+        _ensure_scan_state(dev)
         nb = L.ifl_workspace_bytes(OP_INVERSE, B, C, H, W, KH, KW, flags)
         ws = _ws(nb, dev)
         rc = L.ifl_inverse_f32(_ptr(x), _ptr(w), _ptr(out), B, C, H, W, KH, KW, _order(order), flags, _ptr(ws), nb,
@@ -198,6 +224,7 @@ def unit_inverse(x, ws4, flags=0, carries=None):
     zs = [torch.empty_like(x) for _ in range(4)]
     L = lib()
     with torch.cuda.device(dev):
+        _ensure_scan_state(dev)
         nb = L.ifl_unit_workspace_bytes(OP_INVERSE, B, C, H, W, KH, KW, flags)
         ws = _ws(nb, dev)
         wp, zp = _ptr4(ws4), _ptr4(zs)
@@ -217,6 +244,7 @@ def unit_backward(g, zs, ws4, flags=0, carries=None):
     dws = [torch.empty_like(w) for w in ws4]
     L = lib()
     with torch.cuda.device(dev):
+        _ensure_scan_state(dev)
         nb = L.ifl_unit_workspace_bytes(OP_BACKWARD, B, C, H, W, KH, KW, flags)
         ws = _ws(nb, dev)
         cp = _ptr4(carries) if carries is not None else None
@@ -278,6 +306,7 @@ def backward(g, z, w, order="TL", flags=0, x=None, recon_weight=0.0, need_dx=Tru
     rl = torch.zeros(1, dtype=torch.float32, device=dev) if recon else None
     L = lib()
     with torch.cuda.device(dev):
+        _ensure_scan_state(dev)
         nb = L.ifl_workspace_bytes(OP_BACKWARD, B, C, H, W, KH, KW, flags)
         if need_dx and not recon:  # no activation-sized temporaries needed: fold (+ dW partials)
             nb = L.ifl_workspace_bytes(OP_DY, B, C, H, W, KH, KW, flags)

@@ -48,6 +48,7 @@ def test_version_and_workspace(H):
     assert L.ifl_workspace_bytes(H.OP_INVERSE, -1, 64, 32, 32, 3, 3, 0) == 0
     assert L.ifl_conv2d_workspace_bytes(8, 4, 4, 8, 8, 3, 3, 1, 1) >= 4 * 4 * 9 * 4
     assert L.ifl_carry_bytes(64, 3, 3) >= 256 + 2 * 64 * 64 * 9 * 4 and L.ifl_carry_bytes(0, 3, 3) == 0
+    assert L.ifl_scan_state_bytes() >= 128 * 64 * 1024  # generations + mailbox of 128 images (caller-owned block)
 
 
 def test_argument_validation_without_gpu(H):

@@ -431,3 +431,29 @@ def test_split_scan_streams_and_graph_replay(H):
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(zg, refs[k]), k
+
+
+def test_scan_state_is_caller_owned(H):
+    """The split scan runs only on a block the caller registered (ifl_scan_state_register: the library never allocates);
+    without one the whole-image kernel computes the same bits; a block that is too small is refused."""
+    torch.manual_seed(9)
+    B, C, Hh, Ww, K = 8, 64, 32, 32, 3
+    w = torch.nn.init.dirac_(torch.empty(C, C, K, K)) + 0.02 * torch.randn(C, C, K, K)
+    w[:, -1, -1, -1] = 1.0
+    w = w.cuda()
+    x = torch.randn(B, C, Hh, Ww, device="cuda")
+    z_split = H.inverse(x, w)  # (the host layer registered this stream's block on its first scan)
+    L = H.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    key = (torch.cuda.current_device(), stream)
+    assert key in H._scan_states
+    assert L.ifl_scan_state_register(None, 0, stream) == 0  # forget it: whole-image kernel from now on
+    try:
+        z_whole = H.inverse(x, w)
+        small = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+        assert L.ifl_scan_state_register(small.data_ptr(), small.numel(), stream) == -3  # IFL_EWORKSPACE
+        assert b"bytes needed" in L.ifl_last_error()
+    finally:
+        st = H._scan_states[key]
+        assert L.ifl_scan_state_register(st.data_ptr(), st.numel(), stream) == 0
+    assert torch.equal(z_split, z_whole) and torch.equal(H.inverse(x, w), z_split)

@@ -221,6 +221,13 @@ int ifl_slr_backward_f32(const float *gy, const float *g_logdet, const float *x,
  * from the layer's parameters by the caller (rational_quadratic.py:97-116; no host round trip).  n_bins <= 8.
  * inverse = 0: y = spline(x), logdet[b] = sum log|dy/dx| (may be NULL);  inverse != 0: y = spline^-1(x), logdet[b] =
  * sum log|dy/dx| of the inverse map. */
+/* the knot tables from the layer's parameters (DEVICE vectors: unnormalized widths and heights of n_bins entries,
+ * derivatives of n_bins - 1), rational_quadratic.py:35-46,97-116, and the gradients of the parameters from those of the
+ * tables (g_tables as ifl_rqspline_backward_f32 returns them) */
+int ifl_rqspline_tables_f32(const float *uw, const float *uh, const float *ud, int n_bins, float tail_bound, float *cw,
+                            float *ch, float *dv, ifl_stream_t stream);
+int ifl_rqspline_tables_backward_f32(const float *g_tables, const float *uw, const float *uh, const float *ud, int n_bins,
+                                     float tail_bound, float *g_uw, float *g_uh, float *g_ud, ifl_stream_t stream);
 int ifl_rqspline_f32(const float *x, const float *cw, const float *ch, const float *dv, int n_bins, float tail_bound, float *y,
                      float *logdet, int B, int C, int H, int W, int inverse, void *ws, size_t ws_bytes, ifl_stream_t stream);
 /* backward of the forward direction: gx and g_tables = d loss / d (cw, ch, dv): DEVICE array of 3 (n_bins + 1) floats */

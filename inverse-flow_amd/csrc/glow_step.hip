@@ -652,7 +652,6 @@ __global__ __launch_bounds__(GS_T) void k_rqspline_bwd(const float *__restrict__
                                                        int HW, float tail)
 {
     typedef Dual<7> D;
-    __shared__ float sh[4];
     RqTables t;
 #pragma unroll
     for (int j = 0; j <= NB; ++j) {
@@ -696,7 +695,6 @@ __global__ __launch_bounds__(GS_T) void k_rqspline_bwd(const float *__restrict__
     }
     // one reduction for the 3 (NB + 1) sums: shuffle tree per wave, the four waves' results through LDS, fixed order
     __shared__ float red[4][3 * (NB + 1)];
-    (void)sh;
 #pragma unroll
     for (int j = 0; j <= NB; ++j) {
         float s0 = gcw[j], s1 = gch[j], s2 = gdv[j];
@@ -725,6 +723,63 @@ __global__ __launch_bounds__(64) void k_table_sums(const float *__restrict__ tpa
     for (size_t p = threadIdx.x; p < planes; p += 64) s += tpart[p * ne + e];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if (threadIdx.x == 0) out[e] = s;
+}
+
+// ---- knot tables of the shared-weight spline from its parameters (rational_quadratic.py:35-46,97-116) and the way back.
+// 3 n_bins - 1 numbers in, 3 (n_bins + 1) out: one thread; replaces ~25 eager launches each way.
+//   cw_j = 2T cum_j - T,  cum_j = sum_{i<j} (m + (1 - m K) softmax(uw)_i),  cw_0 = -T, cw_K = T   (ch likewise from uh)
+//   dv_j = m + softplus(ud_{j-1} + c) for 0 < j < K,  dv_0 = dv_K = m + softplus(c),  c = log(e^{1-m} - 1),  m = 1e-6
+__global__ void k_rq_tables(const float *__restrict__ uw, const float *__restrict__ uh, const float *__restrict__ ud,
+                            float *__restrict__ cw, float *__restrict__ ch, float *__restrict__ dv, int K, float T)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float m = 1e-6f, c = logf(expf(1.0f - m) - 1.0f);
+    for (int which = 0; which < 2; ++which) {
+        const float *u = which ? uh : uw;
+        float *out = which ? ch : cw;
+        float mx = u[0];
+        for (int i = 1; i < K; ++i) mx = fmaxf(mx, u[i]);
+        float den = 0.f;
+        for (int i = 0; i < K; ++i) den += expf(u[i] - mx);
+        float cum = 0.f;
+        out[0] = -T;
+        for (int i = 0; i < K; ++i) {
+            cum += m + (1.0f - m * K) * (expf(u[i] - mx) / den);
+            out[i + 1] = i + 1 == K ? T : 2.0f * T * cum - T;
+        }
+    }
+    for (int j = 0; j <= K; ++j) {
+        const float a = (j == 0 || j == K) ? c : ud[j - 1] + c;
+        dv[j] = m + (fmaxf(a, 0.f) + log1pf(expf(-fabsf(a))));
+    }
+}
+// g_tables = (g_cw, g_ch, g_dv), 3 (K + 1) floats -> gradients of the parameters
+__global__ void k_rq_tables_bwd(const float *__restrict__ gt, const float *__restrict__ uw, const float *__restrict__ uh,
+                                const float *__restrict__ ud, float *__restrict__ guw, float *__restrict__ guh,
+                                float *__restrict__ gud, int K, float T)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float m = 1e-6f, c = logf(expf(1.0f - m) - 1.0f);
+    for (int which = 0; which < 2; ++which) {
+        const float *u = which ? uh : uw;
+        const float *g = gt + which * (K + 1);
+        float *out = which ? guh : guw;
+        float mx = u[0];
+        for (int i = 1; i < K; ++i) mx = fmaxf(mx, u[i]);
+        float den = 0.f;
+        for (int i = 0; i < K; ++i) den += expf(u[i] - mx);
+        // g_v_i = (1 - m K) 2T sum_{j = i+1}^{K-1} g_knot_j  (the end knots are constants)
+        float dot = 0.f, tail = 0.f;
+        float gv[RQ_MAXB];
+        for (int i = K - 1; i >= 0; --i) {
+            gv[i] = (1.0f - m * K) * 2.0f * T * tail;
+            if (i >= 1) tail += g[i]; // knot i is fed by v_0 .. v_{i-1}
+        }
+        for (int i = 0; i < K; ++i) dot += (expf(u[i] - mx) / den) * gv[i];
+        for (int i = 0; i < K; ++i) out[i] = (expf(u[i] - mx) / den) * (gv[i] - dot);
+    }
+    const float *gd = gt + 2 * (K + 1);
+    for (int j = 1; j < K; ++j) gud[j - 1] = gd[j] / (1.0f + expf(-(ud[j - 1] + c)));
 }
 
 static int rq_check(const char *who, const float *cw, const float *ch, const float *dv, int nb)
@@ -771,6 +826,33 @@ int ifl_slr_backward_f32(const float *gy, const float *g_logdet, const float *x,
     if (!gy || !x || !gx) IFL_FAIL(IFL_EINVAL, "ifl_slr_backward_f32: null pointer");
     hipLaunchKernelGGL(k_slr_bwd, dim3((unsigned)((size_t)B * C)), dim3(GS_T), 0, (hipStream_t)stream, gy, g_logdet, x, gx, C, H * W,
                        alpha);
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+
+/* parameters (DEVICE: n_bins, n_bins, n_bins - 1 floats) -> knot tables (DEVICE: n_bins + 1 floats each) */
+int ifl_rqspline_tables_f32(const float *uw, const float *uh, const float *ud, int n_bins, float tail_bound, float *cw,
+                            float *ch, float *dv, ifl_stream_t stream)
+{
+    clear_error();
+    if (n_bins < 1 || n_bins > RQ_MAXB) IFL_FAIL(IFL_EUNSUPPORTED, "ifl_rqspline_tables_f32: n_bins=%d (1..%d supported)", n_bins, RQ_MAXB);
+    if (!uw || !uh || (!ud && n_bins > 1) || !cw || !ch || !dv) IFL_FAIL(IFL_EINVAL, "ifl_rqspline_tables_f32: null pointer");
+    hipLaunchKernelGGL(k_rq_tables, dim3(1), dim3(64), 0, (hipStream_t)stream, uw, uh, ud, cw, ch, dv, n_bins, tail_bound);
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+
+/* g_tables (DEVICE, 3 (n_bins + 1) floats: d loss / d cw, ch, dv) -> gradients of the three parameter vectors */
+int ifl_rqspline_tables_backward_f32(const float *g_tables, const float *uw, const float *uh, const float *ud, int n_bins,
+                                     float tail_bound, float *g_uw, float *g_uh, float *g_ud, ifl_stream_t stream)
+{
+    clear_error();
+    if (n_bins < 1 || n_bins > RQ_MAXB)
+        IFL_FAIL(IFL_EUNSUPPORTED, "ifl_rqspline_tables_backward_f32: n_bins=%d (1..%d supported)", n_bins, RQ_MAXB);
+    if (!g_tables || !uw || !uh || (!ud && n_bins > 1) || !g_uw || !g_uh || (!g_ud && n_bins > 1))
+        IFL_FAIL(IFL_EINVAL, "ifl_rqspline_tables_backward_f32: null pointer");
+    hipLaunchKernelGGL(k_rq_tables_bwd, dim3(1), dim3(64), 0, (hipStream_t)stream, g_tables, uw, uh, ud, g_uw, g_uh, g_ud, n_bins,
+                       tail_bound);
     IFL_HIP(hipGetLastError());
     return IFL_OK;
 }

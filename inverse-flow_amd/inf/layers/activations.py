@@ -10,6 +10,8 @@ SmoothLeakyRelu and SplineActivation (shared weights) run 4-D CUDA inputs throug
     and the per-element spline with its derivative sums is one kernel each way (ifl_rqspline_f32 / _backward_f32).
 Anything else (other dimensionalities, CPU tensors, individual weights) takes the reference's torch expressions.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -125,6 +127,26 @@ def spline_tables(unnormalized_widths, unnormalized_heights, unnormalized_deriva
     return cw, ch, dv
 
 
+class _TablesFn(torch.autograd.Function):
+    """parameters -> knot tables in one launch each way (ifl_rqspline_tables_f32 / _backward_f32) instead of the ~25
+    eager kernels of spline_tables() and as many again in its autograd backward"""
+
+    @staticmethod
+    def forward(ctx, uw, uh, ud, tail_bound):
+        uw, uh, ud = uw.contiguous(), uh.contiguous(), ud.contiguous()
+        ctx.save_for_backward(uw, uh, ud)
+        ctx.tail_bound = tail_bound
+        return H.rqspline_tables(uw, uh, ud, tail_bound)
+
+    @staticmethod
+    def backward(ctx, gcw, gch, gdv):
+        uw, uh, ud = ctx.saved_tensors
+        z = lambda g, n: torch.zeros(n, device=uw.device) if g is None else g
+        n = uw.numel() + 1
+        gt = torch.stack([z(gcw, n), z(gch, n), z(gdv, n)]).float().contiguous()
+        return (*H.rqspline_tables_backward(gt, uw, uh, ud, ctx.tail_bound), None)
+
+
 class _SplineFn(torch.autograd.Function):
     @staticmethod
     @_fwd32
@@ -163,6 +185,11 @@ class SplineActivation(FlowActivationLayer):
         return _hip_ok(input) and not self.individual_weights and 1 <= self.n_bins <= 8
 
     def _tables(self):
+        p = self.unnormalized_widths
+        if (p.is_cuda and p.dtype == torch.float32 and not self.individual_weights and 2 <= self.n_bins <= 8
+                and not os.environ.get("IFL_TORCH_SPLINE_TABLES")):  # (the switch is for A/B timing)
+            return _TablesFn.apply(self.unnormalized_widths, self.unnormalized_heights, self.unnormalized_derivatives,
+                                   float(self.tail_bound))
         return spline_tables(self.unnormalized_widths, self.unnormalized_heights, self.unnormalized_derivatives,
                              float(self.tail_bound))
 

@@ -54,6 +54,8 @@ SIGNATURES = {
     "ifl_activation_workspace_bytes": (_sz, [_i, _i, _i]),
     "ifl_slr_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "ifl_slr_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "ifl_rqspline_tables_f32": (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
+    "ifl_rqspline_tables_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     "ifl_rqspline_f32": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ifl_rqspline_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
 }
@@ -595,3 +597,28 @@ def rqspline_backward(gy, g_logdet, x, cw, ch, dv, tail_bound):
     _check(rc, "ifl_rqspline_backward_f32")
     gt = gt.view(3, nbins + 1)
     return gx, gt[0], gt[1], gt[2]
+
+
+def rqspline_tables(uw, uh, ud, tail_bound):
+    """(cw, ch, dv) knot tables from the three parameter vectors (one launch; rational_quadratic.py:35-46,97-116)."""
+    nb = uw.numel()
+    dev = uw.device
+    cw, ch, dv = (torch.empty(nb + 1, dtype=torch.float32, device=dev) for _ in range(3))
+    with torch.cuda.device(dev):
+        rc = lib().ifl_rqspline_tables_f32(_ptr(uw), _ptr(uh), _ptr(ud), nb, float(tail_bound), _ptr(cw), _ptr(ch), _ptr(dv),
+                                           _stream())
+    _check(rc, "ifl_rqspline_tables_f32")
+    return cw, ch, dv
+
+
+def rqspline_tables_backward(g_tables, uw, uh, ud, tail_bound):
+    """gradients of the parameter vectors from the (3, n_bins + 1) gradients of the tables"""
+    nb = uw.numel()
+    dev = uw.device
+    guw, guh = torch.empty_like(uw), torch.empty_like(uh)
+    gud = torch.empty_like(ud)
+    with torch.cuda.device(dev):
+        rc = lib().ifl_rqspline_tables_backward_f32(_ptr(g_tables), _ptr(uw), _ptr(uh), _ptr(ud), nb, float(tail_bound),
+                                                    _ptr(guw), _ptr(guh), _ptr(gud), _stream())
+    _check(rc, "ifl_rqspline_tables_backward_f32")
+    return guw, guh, gud

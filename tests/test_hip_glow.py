@@ -282,3 +282,22 @@ def test_activations_against_oracle(H, oracle, shape):
     assert rel_err(host(xg.grad), xc.grad.numpy()) < 5e-5
     for (k, p), (_, q) in zip(layer.named_parameters(), ref.named_parameters()):
         assert rel_err(host(p.grad), q.grad.numpy()) < 1e-4, k
+
+
+def test_spline_tables_kernels(H, oracle):
+    """knot tables and their way back on the library against the oracle's tables and autograd through this package's
+    torch expressions of the same formulas"""
+    from inf.layers.activations import spline_tables
+    rng = np.random.default_rng(5)
+    for nb, tb in [(5, 10.0), (8, 3.0), (2, 1.5)]:
+        uw, uh, ud = rng.standard_normal(nb), rng.standard_normal(nb), rng.standard_normal(nb - 1)
+        cw, ch, dv = H.rqspline_tables(dev(uw), dev(uh), dev(ud), tb)
+        cw_o, ch_o, dv_o = oracle.spline_tables(uw, uh, ud, tb)
+        assert rel_err(host(cw), cw_o) < TOL and rel_err(host(ch), ch_o) < TOL and rel_err(host(dv), dv_o) < TOL
+        tw, th, td = (torch.from_numpy(a).double().requires_grad_(True) for a in (uw, uh, ud))
+        tcw, tch, tdv = spline_tables(tw, th, td, tb)
+        gt = rng.standard_normal((3, nb + 1))
+        ((tcw * torch.from_numpy(gt[0])).sum() + (tch * torch.from_numpy(gt[1])).sum() + (tdv * torch.from_numpy(gt[2])).sum()).backward()
+        guw, guh, gud = H.rqspline_tables_backward(dev(gt), dev(uw), dev(uh), dev(ud), tb)
+        assert rel_err(host(guw), tw.grad.numpy()) < TOL and rel_err(host(guh), th.grad.numpy()) < TOL
+        assert rel_err(host(gud), td.grad.numpy()) < TOL

@@ -40,3 +40,4 @@ torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / n * 1e3
 print("Glow level, %d steps of [inv_flow 2x2, spline, coupling(256)] at (%d, 12, 16, 16): %.2f ms per forward+backward, %.3f ms per step"
       % (NSTEP, B, ms, ms / NSTEP))
+

@@ -1,47 +1,47 @@
-"""Operator surface of a flow layer (reference: inf/layers/flowlayer.py:7-51).
+"""Operator surface of a flow layer (reference surface: inf/layers/flowlayer.py:7-51).
 
-forward(input, context) -> (output, log|det J|); reverse(input, context) -> input of forward;
-logdet(input, context).  ModifiedGradFlowLayer adds the `compute_expensive` switch that selects
-the exact (dense) computation instead of the self-normalised one.
-"""
+A layer maps `forward(input, context) -> (output, log|det J| per sample)`, undoes it with `reverse(input, context)` and
+reports `logdet(input, context)`.  Layers with a self-normalised gradient (ModifiedGradFlowLayer) take one more
+argument, `compute_expensive`, which selects the exact dense computation; preprocessing layers are only a marker (their
+log-det is left out of FlowSequential.non_preprocessing_logdet)."""
 import abc
 
-import torch.nn as nn
+from torch import nn
+
+_SURFACE = ("forward", "reverse", "logdet")
+
+
+def _abstract(name, with_switch):
+    if with_switch:
+        def method(self, input, context=None, compute_expensive=False):
+            raise NotImplementedError(name)
+    else:
+        def method(self, input, context=None):
+            raise NotImplementedError(name)
+    method.__name__ = name
+    return abc.abstractmethod(method)
 
 
 class FlowLayer(nn.Module, metaclass=abc.ABCMeta):
-    @abc.abstractmethod
-    def forward(self, input, context=None):
-        ...
-
-    @abc.abstractmethod
-    def reverse(self, input, context=None):
-        ...
-
-    @abc.abstractmethod
-    def logdet(self, input, context=None):
-        ...
+    """Abstract: forward, reverse, logdet."""
 
 
 class ModifiedGradFlowLayer(FlowLayer):
-    @abc.abstractmethod
-    def forward(self, input, context=None, compute_expensive=False):
-        ...
+    """Abstract: the same three methods with the `compute_expensive` switch."""
 
-    @abc.abstractmethod
-    def reverse(self, input, context=None, compute_expensive=False):
-        ...
 
-    @abc.abstractmethod
-    def logdet(self, input, context=None, compute_expensive=False):
-        ...
+for _name in _SURFACE:
+    setattr(FlowLayer, _name, _abstract(_name, False))
+    setattr(ModifiedGradFlowLayer, _name, _abstract(_name, True))
+FlowLayer.__abstractmethods__ = frozenset(_SURFACE)
+ModifiedGradFlowLayer.__abstractmethods__ = frozenset(_SURFACE)
 
 
 class PreprocessingFlowLayer(FlowLayer):
-    """Marker base class: layers whose log-det is excluded from non_preprocessing_logdet."""
+    """Marker base class (dequantisation, normalisation)."""
 
 
 def mark_expensive(func):
-    """Tag a method as the exact/expensive computation (flowlayer.py:49-51)."""
+    """Tag a method as the exact / expensive computation (flowlayer.py:49-51)."""
     func._expensive_computation = True
     return func

@@ -1,71 +1,61 @@
-"""Squeeze / UnSqueeze on the HIP library (reference: inf/layers/squeeze.py:5-52): the space-to-depth permutation
-as one pass (ifl_squeeze_f32) instead of view + permute + contiguous; zero log-det."""
+"""Squeeze / UnSqueeze on the HIP library (reference surface: inf/layers/squeeze.py:5-52).
+
+space_to_depth maps (B, C, H, W) to (B, 4C, H/2, W/2) with output channel 4c + 2dy + dx holding x[c, 2h+dy, 2w+dx]
+(the ordering of squeeze.py:5-13) -- which is torch's pixel_unshuffle with factor 2; depth_to_space is its inverse
+(pixel_shuffle).  CUDA fp32 tensors take one pass of libinvflow_hip (ifl_squeeze_f32) in either direction, and the
+gradient of one permutation is the other; everything else uses the torch primitives.  The log-det is zero."""
 import torch
+import torch.nn.functional as F
 
 import invflow_hip as H
 
 from .flowlayer import FlowLayer
 
 
-class _S2D(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x):
-        return H.space_to_depth(x.contiguous())
+class _Permute(torch.autograd.Function):
+    """to_depth = True: space_to_depth; False: depth_to_space.  Backward: the opposite direction."""
 
     @staticmethod
-    def backward(ctx, g):
-        return H.depth_to_space(g.contiguous())
-
-
-class _D2S(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x):
-        return H.depth_to_space(x.contiguous())
+    def forward(ctx, x, to_depth):
+        ctx.to_depth = to_depth
+        x = x.contiguous()
+        return H.space_to_depth(x) if to_depth else H.depth_to_space(x)
 
     @staticmethod
     def backward(ctx, g):
-        return H.space_to_depth(g.contiguous())
+        g = g.contiguous()
+        return (H.depth_to_space(g) if ctx.to_depth else H.space_to_depth(g)), None
 
 
-def _hip_ok(x):
+def _on_library(x):
     return x.dim() == 4 and x.is_cuda and x.dtype == torch.float32
 
 
 def space_to_depth(x):
-    if _hip_ok(x):
-        return _S2D.apply(x)
-    xs = x.size()  # squeeze.py:5-13
-    x = x.view(xs[0], xs[1], xs[2] // 2, 2, xs[3] // 2, 2)
-    x = x.permute((0, 1, 3, 5, 2, 4)).contiguous()
-    return x.view(xs[0], xs[1] * 4, xs[2] // 2, xs[3] // 2)
+    return _Permute.apply(x, True) if _on_library(x) else F.pixel_unshuffle(x, 2)
 
 
 def depth_to_space(x):
-    if _hip_ok(x):
-        return _D2S.apply(x)
-    xs = x.size()  # squeeze.py:16-25
-    x = x.view(xs[0], xs[1] // 4, 2, 2, xs[2], xs[3])
-    x = x.permute((0, 1, 4, 2, 5, 3)).contiguous()
-    return x.view(xs[0], xs[1] // 4, xs[2] * 2, xs[3] * 2)
+    return _Permute.apply(x, False) if _on_library(x) else F.pixel_shuffle(x, 2)
 
 
-class Squeeze(FlowLayer):
+class _SqueezeBase(FlowLayer):
+    _down = True  # forward squeezes space into depth
+
     def forward(self, input, context=None):
-        return space_to_depth(input), self.logdet(input, context)
+        out = space_to_depth(input) if self._down else depth_to_space(input)
+        return out, self.logdet(input, context)
 
     def reverse(self, input, context=None):
-        return depth_to_space(input)
+        return depth_to_space(input) if self._down else space_to_depth(input)
 
     def logdet(self, input, context=None):
-        return input.new_zeros(len(input))
+        return input.new_zeros(input.shape[0])
 
 
-class UnSqueeze(FlowLayer):
-    def forward(self, input, context=None):
-        return depth_to_space(input), self.logdet(input, context)
+class Squeeze(_SqueezeBase):
+    _down = True
 
-    def reverse(self, input, context=None):
-        return space_to_depth(input)
 
-    def logdet(self, input, context=None):
-        return input.new_zeros(len(input))
+class UnSqueeze(_SqueezeBase):
+    _down = False

@@ -316,3 +316,44 @@ def test_mini_glow_stack_end_to_end():
                 p.add_(eps * d)
         numeric = float(lp_ - lm_) / (2 * eps)
         assert abs(analytic - numeric) < 3e-2 * abs(numeric) + 0.3, (name, analytic, numeric)
+
+
+def test_level_captures_into_graphs():
+    """Every launch of the library is stream-ordered and allocation-free, so a FlowSequential of its layers goes through
+    torch.cuda.make_graphed_callables (forward and backward graphs); replays give the eager model's loss and gradients."""
+    import copy
+    from inf.layers.activations import SmoothLeakyRelu, SplineActivation
+    from inf.layers.coupling import Coupling
+    from inf.layers.flowsequential import FlowSequential
+    from inf.layers.inv_conv import inv_flow_with_pad
+    from inf.train.losses import NegativeGaussianLoss
+    torch.manual_seed(11)
+    B, size = 8, (12, 8, 8)
+    layers = []
+    for order in ("TL", "BR"):
+        layers += [inv_flow_with_pad(12, 12, (3, 3), order=order), SplineActivation(size, tail_bound=4.0), SmoothLeakyRelu(0.3),
+                   Coupling(size, width=16)]
+    eager = FlowSequential(NegativeGaussianLoss(size=size), *layers).cuda()
+    with torch.no_grad():
+        for m in eager.modules():
+            if isinstance(m, Coupling):
+                for p in m.net.parameters():
+                    p.add_(0.05 * torch.randn_like(p))
+    graphed_model = copy.deepcopy(eager)
+    x = torch.randn(B, *size, device="cuda")
+    xg = x.clone().requires_grad_(True)
+    graphed = torch.cuda.make_graphed_callables(graphed_model, (xg,))  # (before any eager backward of ITS parameters)
+    for it in range(3):  # replays
+        for p in graphed_model.parameters():
+            p.grad = None
+        xg.grad = None
+        z, lp = graphed(xg)
+        (-(lp.sum() / B)).backward()
+    xe = x.clone().requires_grad_(True)
+    ze, lpe = eager(xe)
+    (-(lpe.sum() / B)).backward()
+    assert rel_err(z.detach().cpu().numpy(), ze.detach().cpu().numpy()) < 1e-6
+    assert rel_err(lp.detach().cpu().numpy(), lpe.detach().cpu().numpy()) < 1e-6
+    assert rel_err(xg.grad.cpu().numpy(), xe.grad.cpu().numpy()) < 1e-5
+    for (k, p), (_, q) in zip(graphed_model.named_parameters(), eager.named_parameters()):
+        assert rel_err(p.grad.cpu().numpy(), q.grad.cpu().numpy()) < 1e-5, k

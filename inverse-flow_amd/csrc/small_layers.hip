@@ -81,13 +81,17 @@ int launch_scan_resident(const float *x, const float *wf, float *z, const Geom &
 // keeps the KH*KW sums of a pair in registers.
 template <int KH, int KW>
 __global__ __launch_bounds__(256) void k_wgrad_batchpar(const float *__restrict__ gz, const float *__restrict__ x,
-                                                        float *__restrict__ partial, int C, int H, int W, int pt, int pl)
+                                                        float *__restrict__ partial, int C, int H, int W, int pt, int pl,
+                                                        int nsplit)
 {
     extern __shared__ float smem[];
     constexpr int NT = KH * KW;
     const int HW = H * W, PG = HW | 1, WH = W + KW - 1, HH = H + KH - 1, PX = (HH * WH) | 1;
     float *gs = smem, *xs = smem + C * PG;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    // blockIdx.x = image * nsplit + part: a part sums the output rows [r0, r1) of its image (small batches: more
+    // workgroups than images); its slab is partial[blockIdx.x]
+    const int b = blockIdx.x / nsplit, part = blockIdx.x % nsplit, tid = threadIdx.x;
+    const int r0 = part * H / nsplit, r1 = (part + 1) * H / nsplit, HR = r1 - r0;
     for (int i = tid; i < C * PX; i += 256) xs[i] = 0.f;
     __syncthreads();
     for (int i = tid; i < C * HW; i += 256) {
@@ -98,12 +102,12 @@ __global__ __launch_bounds__(256) void k_wgrad_batchpar(const float *__restrict_
     }
     __syncthreads();
     // fewer pairs than threads: the image rows are cut into S segments per pair, summed afterwards in order
-    const int CC = C * C, S = CC >= 256 ? 1 : (256 / CC < H ? 256 / CC : H);
+    const int CC = C * C, S = CC >= 256 ? 1 : (256 / CC < HR ? 256 / CC : (HR > 0 ? HR : 1));
     float *red = xs + C * PX; // [pair][segment][tap], only when S > 1
     for (int it = tid; it < CC * S; it += 256) {
         const int pr = it / S, sg = it % S;
         const int co = pr / C, ci = pr % C;
-        const int oh0 = sg * H / S, oh1 = (sg + 1) * H / S;
+        const int oh0 = r0 + sg * HR / S, oh1 = r0 + (sg + 1) * HR / S;
         const float *gp = gs + co * PG, *xp = xs + ci * PX;
         float acc[NT];
 #pragma unroll
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256) void k_wgrad_batchpar(const float *__restrict_
 #pragma unroll
                     for (int kw = 0; kw < KW; ++kw) acc[kh * KW + kw] = fmaf(g, xp[(oh + kh) * WH + ow + kw], acc[kh * KW + kw]);
             }
-        float *out = S > 1 ? red + (size_t)it * NT : partial + ((size_t)b * CC + pr) * NT;
+        float *out = S > 1 ? red + (size_t)it * NT : partial + ((size_t)blockIdx.x * CC + pr) * NT;
 #pragma unroll
         for (int t = 0; t < NT; ++t) out[t] = acc[t];
     }
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256) void k_wgrad_batchpar(const float *__restrict_
             const int pr = o / NT, t = o % NT;
             float a = 0.f;
             for (int sg = 0; sg < S; ++sg) a += red[((size_t)pr * S + sg) * NT + t];
-            partial[(size_t)b * CC * NT + o] = a;
+            partial[(size_t)blockIdx.x * CC * NT + o] = a;
         }
     }
 }
@@ -157,7 +161,8 @@ __global__ __launch_bounds__(256) void k_wgrad_batchred(const float *__restrict_
     dw[o] = val;
 }
 
-size_t wgrad_small_workspace_bytes(int B, int C, int KH, int KW) { return (size_t)B * C * C * KH * KW * sizeof(float) + 256; }
+// (room for two slabs per image: small batches split an image's rows over two workgroups)
+size_t wgrad_small_workspace_bytes(int B, int C, int KH, int KW) { return (size_t)2 * B * C * C * KH * KW * sizeof(float) + 256; }
 
 static size_t wgrad_small_lds_bytes(int C, int H, int W, int KH, int KW)
 {
@@ -179,14 +184,15 @@ int launch_wgrad_small(const float *gz, const float *x, float *dw, void *ws, int
 {
     float *partial = (float *)ws;
     const size_t lds = wgrad_small_lds_bytes(C, H, W, KH, KW);
+    const int nsplit = (B <= 128 && H >= 8) ? 2 : 1; // (batches that leave half the compute units idle)
     if (KH == 2)
-        hipLaunchKernelGGL((k_wgrad_batchpar<2, 2>), dim3(B), dim3(256), lds, s, gz, x, partial, C, H, W, pt, pl);
+        hipLaunchKernelGGL((k_wgrad_batchpar<2, 2>), dim3(B * nsplit), dim3(256), lds, s, gz, x, partial, C, H, W, pt, pl, nsplit);
     else
-        hipLaunchKernelGGL((k_wgrad_batchpar<3, 3>), dim3(B), dim3(256), lds, s, gz, x, partial, C, H, W, pt, pl);
+        hipLaunchKernelGGL((k_wgrad_batchpar<3, 3>), dim3(B * nsplit), dim3(256), lds, s, gz, x, partial, C, H, W, pt, pl, nsplit);
     IFL_HIP(hipGetLastError());
     const int NO = C * C * KH * KW;
-    hipLaunchKernelGGL(k_wgrad_batchred, dim3((NO + 63) / 64), dim3(256), 0, s, partial, dw, B, C, KH, KW, scale, mask_mode,
-                       mkh, mkw);
+    hipLaunchKernelGGL(k_wgrad_batchred, dim3((NO + 63) / 64), dim3(256), 0, s, partial, dw, B * nsplit, C, KH, KW, scale,
+                       mask_mode, mkh, mkw);
     IFL_HIP(hipGetLastError());
     return IFL_OK;
 }

@@ -1027,11 +1027,11 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_split(const float *__res
 //   slot NT-1     :  L^-1                (transposed: L^-T)
 // apack[wv][s][q][hl][lane][j] (fp16),  lane = m + 16*gk holds row c = 16wv+m, k = 32q + 8gk + j.
 //
-// Grid = NT slots x C/16 row groups.  Every workgroup first inverts L in LDS (fp64) by 16x16
-// blocks -- diagonal blocks by substitution (16 dependent steps), off-diagonal blocks
-// X_ij = -X_ii (sum_k L_ik X_kj) level by level -- which cuts the 64-step serial substitution of
-// the exact solver's channel loop (solve_mc.py:96-109) to ~16 + 2(C/16-1) short dependent stages,
-// then forms its 16 rows of the product and splits them into fp16 hi / lo*2^11.
+// Grid = NT slots x C/16 row groups.  Every workgroup inverts the 16x16 DIAGONAL blocks of L in LDS (fp64, by
+// substitution: 16 dependent steps) and then obtains its 16 rows of the slot by a block triangular solve
+// X L = W_t on the fp64 matrix cores (C/16 dependent block steps, everything in registers) -- which cuts the
+// 64-step serial substitution of the exact solver's channel loop (solve_mc.py:96-109) to ~16 + C/16 short
+// dependent stages and never forms the full inverse -- and splits them into fp16 hi / lo*2^11.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ size_t w_index2(int co, int ci, int dh, int dw, int C, int KH, int KW, int flipH,
                                            int flipW)
@@ -1153,77 +1153,101 @@ template <int C> __global__ __launch_bounds__(256) void k_foldpack(FoldJobs jobs
     __syncthreads();
     IFL_FSTAMP(); // 1: diagonal blocks
 
-    // ---- off-diagonal blocks, one block-distance at a time, on the fp64 matrix cores: X_ij = -X_ii (sum_k L_ik X_kj).
-    //      One wave per pair (i, j) of a distance.  v_mfma_f64_16x16x4_f64 layouts (tools/mfma_f64_layout_probe.hip):
-    //      A[i = l%16][k = l/16], B[k = l/16][j = l%16] one double per lane, D[i = 4v + l/16][j = l%16] in register v
-    //      -- so register kc of a result IS the B operand of k-chunk kc of the next product: the inner sum S goes
-    //      straight into the second product without leaving the registers. ----------------------------------------
+    // ---- this workgroup's 16 rows of the slot by a block triangular SOLVE (fp64 matrix cores), not by a product with
+    //      the full inverse: X L = R (R = the 16 rows of W_t, or of the identity for the last slot), block by block:
+    //          normal      X_j = (R_j - sum_{k>j} X_k L_kj) L_jj^-1       j = NBK-1 .. 0
+    //          transposed  X_j = (R_j - sum_{k<j} X_k L_jk^T) L_jj^-T     j = 0 .. NBK-1     (X = W_t^T L^-T)
+    //      Only the diagonal blocks of L^-1 (above) are needed.  The solve runs on the TRANSPOSES Y_j = X_j^T, so that
+    //      every intermediate is a right-hand operand: v_mfma_f64_16x16x4_f64 layouts (tools/mfma_f64_layout_probe.hip):
+    //      A[i = l%16][k = l/16], B[k = l/16][j = l%16], D[i = 4v + l/16][j = l%16] in register v -- register kc of a
+    //      result IS the B operand of k-chunk kc of the next product, nothing leaves the registers:
+    //          Y_j = Dinv_jj^T (R_j^T - sum_k L_kj^T Y_k)   resp.   Y_j = Dinv_jj (R_j^T - sum_k L_jk Y_k)
+    //      One wave: 40 dependent-ish MFMAs instead of the three barrier-separated levels of the off-diagonal inverse plus
+    //      a 16-deep product chain per wave.  Y_j[4v + lk][li] = X[row li][column 16j + 4v + lk].
     typedef double doublex4 __attribute__((ext_vector_type(4)));
     const int wvf = tid / 64, lf = tid % 64, li = lf % 16, lk = lf / 16;
-    {
-#pragma unroll 1
-        for (int dist = 1; dist < NBK; ++dist) {
-            const int npairs = NBK - dist;
-            const int bi = wvf + dist, bj = wvf;
-            if (wvf < npairs) {
-                doublex4 acc = {0.0, 0.0, 0.0, 0.0};
-                for (int kb = bj; kb < bi; ++kb) {
+    if (wvf == 0) {
+        doublex4 Ys[NBK]; // by solve step (compile-time index); step p solved block (transposed ? p : NBK-1-p)
+        // every A operand (entries of L and of the diagonal blocks of L^-1) up front: none depends on the chain, and
+        // an LDS load + conversion in front of each MFMA would sit on it
+        double aL[NBK][NBK][4], aD[NBK][4];
 #pragma unroll
-                    for (int kc = 0; kc < 4; ++kc) {
-                        const int k = 16 * kb + 4 * kc + lk;
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)sL[(16 * bi + li) * LP + k], sX[k * XP + 16 * bj + li], acc, 0, 0, 0);
-                    }
+        for (int step = 0; step < NBK; ++step) {
+            const int j = transposed ? step : NBK - 1 - step;
+#pragma unroll
+            for (int p = 0; p < NBK; ++p)
+                if (p < step) {
+                    const int k = transposed ? p : NBK - 1 - p;
+#pragma unroll
+                    for (int kc = 0; kc < 4; ++kc)
+                        aL[step][p][kc] = transposed ? -(double)sL[(16 * j + li) * LP + 16 * k + 4 * kc + lk]
+                                                     : -(double)sL[(16 * k + 4 * kc + lk) * LP + 16 * j + li];
                 }
-                doublex4 res = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int kc = 0; kc < 4; ++kc) // X_ii is lower triangular: its upper entries are exactly zero in sX
-                    res = __builtin_amdgcn_mfma_f64_16x16x4f64(sX[(16 * bi + li) * XP + 16 * bi + 4 * kc + lk], acc[kc], res, 0, 0, 0);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) sX[(16 * bi + 4 * v + lk) * XP + 16 * bj + li] = -res[v];
-            }
-            __syncthreads();
+            for (int kc = 0; kc < 4; ++kc)
+                aD[step][kc] = transposed ? sX[(16 * j + li) * XP + 16 * j + 4 * kc + lk]
+                                          : sX[(16 * j + 4 * kc + lk) * XP + 16 * j + li];
         }
-    }
-
-    IFL_FSTAMP(); // 2: off-diagonal blocks
-    // ---- this workgroup's 16 rows of the slot: product (fp64 matrix cores), split, pack -------------------------
-    // wave = 16 columns kc; lane (li, lk) ends up with rows cl = 4v + lk of column kc = 16 wave + li
-    if (wvf < C / 16) {
-        const int kc = 16 * wvf + li;
-        doublex4 acc = {0.0, 0.0, 0.0, 0.0};
-        if (s == NT - 1) {
+#pragma unroll
+        for (int step = 0; step < NBK; ++step) {
+            const int j = transposed ? step : NBK - 1 - step;
+            // acc = R_j^T (D layout: element (4v + lk, li) = R[row li][column 16j + 4v + lk])
+            doublex4 acc;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int c = 16 * rgrp + 4 * v + lk;
-                acc[v] = transposed ? sX[kc * XP + c] : sX[c * XP + kc];
+                const int col = 16 * j + 4 * v + lk;
+                acc[v] = s == NT - 1 ? (col == 16 * rgrp + li ? 1.0 : 0.0) : (double)sW[col * 16 + li];
             }
-        } else {
-            // normal:     (W_t L^-1)[c][kc]     = sum_m W_t[c][m] Linv[m][kc]   (Linv[m][kc] = 0 for m < kc)
-            // transposed: (W_t^T L^-T)[c][kc]   = sum_m W_t[m][c] Linv[kc][m]   (Linv[kc][m] = 0 for m > kc)
-            // (sW holds the row c of either form as sW[m][c]; the zeros of L^-1 are stored: fixed trip count)
-#pragma unroll 4
-            for (int mc = 0; mc < C / 4; ++mc) {
-                const int m = 4 * mc + lk;
-                const double bx = transposed ? sX[kc * XP + m] : sX[m * XP + kc];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)sW[m * 16 + li], bx, acc, 0, 0, 0);
+            // acc -= sum_k (L_kj^T | L_jk) Y_k over the blocks solved so far
+#pragma unroll
+            for (int p = 0; p < NBK; ++p) {
+                if (p < step) {
+                    // A[i = li][kk = 4kc + lk] = -(L_kj^T)[i][kk] = -L[16k + kk][16j + i]   (normal)
+                    //                          = -L_jk[i][kk]     = -L[16j + i][16k + kk]   (transposed)
+#pragma unroll
+                    for (int kc = 0; kc < 4; ++kc) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[step][p][kc], Ys[p][kc], acc, 0, 0, 0);
+                }
             }
+            // Y_j = (Dinv_jj^T | Dinv_jj) acc
+            doublex4 res = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int v = 0; v < 4; ++v) acc[v] = -acc[v];
+            for (int kc = 0; kc < 4; ++kc) res = __builtin_amdgcn_mfma_f64_16x16x4f64(aD[step][kc], acc[kc], res, 0, 0, 0);
+            Ys[step] = res;
         }
+        // the 16 x C result (fp32, signed) goes to LDS (sW is free again) so that all four waves can pack it
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int cl = 4 * v + lk, c = 16 * rgrp + cl;
-            const float val = (float)acc[v];
-            // fp32 copy [slot][kc][c] of the layer's own channels for the fp32 fallback scan
-            if (wf32 && kc < g.C && c < g.C) wf32[((size_t)s * g.C + kc) * g.C + c] = val;
-            const _Float16 hi = (_Float16)val;
-            const _Float16 lo = (_Float16)((val - (float)hi) * LO_SCALE);
-            const int q = kc / 32, gk = (kc % 32) / 8, j = kc % 8;
-            const size_t base = ((((size_t)rgrp * NT + s) * NQ + q) * 2) * 64 * 8;
-            apack[base + (size_t)(cl + 16 * gk) * 8 + j] = hi;
-            apack[base + (size_t)64 * 8 + (size_t)(cl + 16 * gk) * 8 + j] = lo;
-        }
+        for (int p = 0; p < NBK; ++p)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int j = transposed ? p : NBK - 1 - p;
+                sW[li * C + 16 * j + 4 * v + lk] = (s == NT - 1 ? 1.f : -1.f) * (float)Ys[p][v];
+            }
     }
+    __syncthreads();
+    // ---- split, pack: a thread owns (row cl, 8 consecutive columns) = one 16-byte piece of the hi plane and one of the
+    //      lo plane of the A-fragment image; the fp32 copy for the fallback scan is written row by row
+    if (tid < 16 * (C / 8)) {
+        const int cl = tid % 16, k8 = tid / 16; // columns 8 k8 .. 8 k8 + 7
+        const int q = k8 / 4, gk = k8 % 4;
+        half8 hi8, lo8;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const float val = sW[cl * C + 8 * k8 + jj];
+            const _Float16 hi = (_Float16)val;
+            hi8[jj] = hi;
+            lo8[jj] = (_Float16)((val - (float)hi) * LO_SCALE);
+        }
+        const size_t base = ((((size_t)rgrp * NT + s) * NQ + q) * 2) * 64 * 8;
+        *(half8 *)(apack + base + (size_t)(cl + 16 * gk) * 8) = hi8;
+        *(half8 *)(apack + base + (size_t)64 * 8 + (size_t)(cl + 16 * gk) * 8) = lo8;
+    }
+    if (wf32)
+        for (int idx = tid; idx < 16 * C; idx += 256) {
+            const int cl = idx % 16, kc = idx / 16, c = 16 * rgrp + cl;
+            // fp32 copy [slot][kc][c] of the layer's own channels for the fp32 fallback scan
+            if (kc < g.C && c < g.C) wf32[((size_t)s * g.C + kc) * g.C + c] = sW[cl * C + kc];
+        }
+    IFL_FSTAMP(); // 2: block solve + pack
     IFL_FSTAMP(); // 3: product + pack
 #ifdef IFL_STAMPS
     if (g_stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0)

@@ -1199,21 +1199,31 @@ template <int C> __global__ __launch_bounds__(256) void k_foldpack(FoldJobs jobs
                 acc[v] = s == NT - 1 ? (col == 16 * rgrp + li ? 1.0 : 0.0) : (double)sW[col * 16 + li];
             }
             // acc -= sum_k (L_kj^T | L_jk) Y_k over the blocks solved so far
+            doublex4 parts[NBK];
 #pragma unroll
             for (int p = 0; p < NBK; ++p) {
                 if (p < step) {
                     // A[i = li][kk = 4kc + lk] = -(L_kj^T)[i][kk] = -L[16k + kk][16j + i]   (normal)
                     //                          = -L_jk[i][kk]     = -L[16j + i][16k + kk]   (transposed)
+                    // (its own accumulator per solved block: the products of different blocks are independent chains)
+                    {
+                        doublex4 part = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int kc = 0; kc < 4; ++kc) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[step][p][kc], Ys[p][kc], acc, 0, 0, 0);
+                        for (int kc = 0; kc < 4; ++kc) part = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[step][p][kc], Ys[p][kc], part, 0, 0, 0);
+                        parts[p] = part;
+                    }
                 }
             }
+#pragma unroll
+            for (int p = 0; p < NBK; ++p)
+                if (p < step) acc += parts[p];
             // Y_j = (Dinv_jj^T | Dinv_jj) acc
             doublex4 res = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc) res = __builtin_amdgcn_mfma_f64_16x16x4f64(aD[step][kc], acc[kc], res, 0, 0, 0);
             Ys[step] = res;
         }
+        IFL_FSTAMP(); // 2: block solve
         // the 16 x C result (fp32, signed) goes to LDS (sW is free again) so that all four waves can pack it
 #pragma unroll
         for (int p = 0; p < NBK; ++p)
@@ -1247,7 +1257,7 @@ template <int C> __global__ __launch_bounds__(256) void k_foldpack(FoldJobs jobs
             // fp32 copy [slot][kc][c] of the layer's own channels for the fp32 fallback scan
             if (kc < g.C && c < g.C) wf32[((size_t)s * g.C + kc) * g.C + c] = sW[cl * C + kc];
         }
-    IFL_FSTAMP(); // 2: block solve + pack
+    IFL_FSTAMP(); // 3: pack
     IFL_FSTAMP(); // 3: product + pack
 #ifdef IFL_STAMPS
     if (g_stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0)

@@ -37,4 +37,4 @@ for part in range(2):
       c = int(full[68 + k]); tot = int(full[64 + k])
       if c:
           print("steps with", name, ":", c, "steps,", tot // c, "cycles each")
-print("fold (workgroup 0):", dict(zip(["loads", "diagonal blocks", "block solve + pack", "-"], both[160:164].tolist())))
+print("fold (workgroup 0):", dict(zip(["loads", "diagonal blocks", "block solve", "pack"], both[160:164].tolist())))

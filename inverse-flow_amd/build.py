@@ -26,7 +26,14 @@ def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, stamps=False):
+    """stamps=True: the development build with the in-kernel cycle stamps (tools/*stamps.py), kept apart from the product
+    library: lib/libinvflow_hip_stamps.so"""
+    global FLAGS, OBJDIR, LIB
+    if stamps:
+        FLAGS = FLAGS + ["-DIFL_STAMPS"]
+        OBJDIR = os.path.join(HERE, "build", "stamps")
+        LIB = os.path.join(LIBDIR, "libinvflow_hip_stamps.so")
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
@@ -62,4 +69,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, stamps="--stamps" in sys.argv))

@@ -97,6 +97,13 @@ struct SplitState {
 };
 size_t scan_state_bytes();
 int scan_state_register(void *state, size_t bytes, hipStream_t s); // (state = NULL: forget this stream's block)
+// The duo form of the scan (scan_duo.hip): one workgroup per 16-row tile, chain waves + helper waves; `state` = the
+// registered block (needed for images of more than 16 rows) or NULL.
+size_t scan_duo_state_bytes();
+int scan_duo_max_images();
+bool scan_duo_supported(const Geom &g);
+int launch_scan_duo(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, int *flags,
+                    const float *wf32, unsigned *amax, void *state, hipStream_t s);
 // amax: optional device word that receives max|z| (atomicMax of float bits; must be cleared beforehand)
 int launch_scan_mfma(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, int *flags,
                      const float *wf32, unsigned *amax, hipStream_t s);

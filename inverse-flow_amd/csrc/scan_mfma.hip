@@ -1418,6 +1418,17 @@ int launch_scan_mfma(const float *x, const void *apack, float *z, const Geom &g,
 {
     const int nt = g.H <= 16 ? 1 : 2;
     const int ct = mfma_padded_channels(g.C);
+    {
+        // bring-up switch (IFL_DUO=0: the round-1 kernels)
+        const char *e = getenv("IFL_DUO");
+        const bool duo = !(e && atoi(e) == 0) && scan_duo_supported(g);
+        const char *ns = getenv("IFL_NO_SPLIT");
+        const bool no_split = ns && atoi(ns);
+        if (duo && nt == 1) return launch_scan_duo(x, apack, z, g, rh, rw, flags, wf32, amax, nullptr, s);
+        char *st = nullptr;
+        if (duo && nt == 2 && !no_split && g.B <= scan_duo_max_images() && 2 * g.B <= device_cus() && (st = split_state(s)))
+            return launch_scan_duo(x, apack, z, g, rh, rw, flags, wf32, amax, st, s);
+    }
 #define IFL_CASE(CC, KK, NN) \
     if (ct == CC && g.KH == KK && g.KW == KK && nt == NN)                                                                   \
         return g.C == CC ? launch_one<CC, KK, KK, NN, false>(x, z, apack, g, rh, rw, flags, wf32, amax, s)                  \

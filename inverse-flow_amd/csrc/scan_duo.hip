@@ -47,7 +47,7 @@ template <int C, int KH, int KW> struct DuoCfg {
     static constexpr int RBB = NPL * 256;  // one row block (16 rows x NPL planes x 16 B)
     static constexpr int SLOTB = 2 * RBB;  // one diagonal: row block 0 (rows above the tile: zero or the hand-off) + the tile
     static constexpr int RINGB = 2 * SLOTB;
-    static constexpr int NXS = 4;          // x quads a row keeps in flight ([row][quad % NXS][channel][4])
+    static constexpr int NXS = 2;          // x quads a row keeps staged ([row][quad % NXS][channel][4])
     static constexpr int XROWB = NXS * C * 16 + 16;
     static constexpr int XSB = 16 * XROWB;
     static constexpr int ZROWB = 2 * C * 16 + 16; // z quads: [row][quad parity][channel][4]
@@ -56,14 +56,14 @@ template <int C, int KH, int KW> struct DuoCfg {
     static constexpr int DUMPB = 4 * 256 + 64 * NW * 8; // where chain lanes outside the image write their r
     static constexpr int NHL = 8;                        // landing slots of mailbox lines (lower part)
     static constexpr int OFF_HALO = OFF_DUMP + DUMPB;
-    static constexpr int OFF_DMY = OFF_HALO + NHL * 1024; // landing of the DMAs no row is due for (1 KiB per helper)
-    static constexpr int LDSB = OFF_DMY + NW * 1024;
+    static constexpr int OFF_DMY = OFF_HALO + NHL * 1024; // landing of the mailbox prefetches no line is due for
+    static constexpr int OFF_BNC = OFF_DMY + NW * 1024;   // bounce buffers: one image row (C channels x 128 B) per helper
+    static constexpr int LDSB = OFF_BNC + NW * (C / 8) * 1024;
     static constexpr int THREADS = 128 * NW;
     static constexpr int G = 4 / NW;       // rows per helper wave that start / finish a quad each step
     static constexpr int PF = 8;           // x quads are requested PF steps before their first use
     static constexpr int PFH = 3;          // mailbox lines are requested PFH steps before they are delivered
     static constexpr int GATE = PFH + 3;   // the lower part starts once the upper part's diagonal 14 + GATE is visible
-    static_assert(PF + 3 < 4 * NXS, "an x quad must be dead before its staging slot is loaded again");
     static_assert(PFH < NHL && PF >= PFH + 2, "the sweep's lead-in covers both prefetches");
     static_assert(4 % NW == 0 && C <= 64, "one DMA / store instruction covers one image row of all channels");
 };
@@ -112,6 +112,100 @@ static constexpr int DUO_LINES = 80;
 static constexpr int DUO_LINEB = 1024;
 static constexpr int DUO_MAX_IMAGES = 128;
 
+// ---- the helper waves' row buffers: accumulator registers a0 .. a127, addressed by NUMBER ----------------------------------
+// Buffer k, register i (16 bytes per lane) is a[4 (k NIM + i) : +3].  They are not C++ variables: the compiler knows them
+// only as registers that every statement below clobbers.  As variables they were moved around between statements -- through
+// scratch registers while loads were in flight when they were targets of asm loads, or by the hundred moves per step when
+// nothing asynchronous targeted them.  Nothing the compiler emits in the helper waves' code uses an accumulator register
+// (their MFMAs are asm with ordinary registers; tests/test_build_checks.py looks at the ISA).
+#define IFL_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
+// buffer <- bounce buffer (NIM reads of 1 KiB apart, complete on return)
+template <int R0, int NIM> __device__ __forceinline__ void rb_take(unsigned la)
+{
+    if constexpr (NIM == 8)
+        asm volatile("ds_read_b128 a[%1:%2], %0\n\tds_read_b128 a[%3:%4], %0 offset:1024\n\tds_read_b128 a[%5:%6], %0 offset:2048\n\t"
+                     "ds_read_b128 a[%7:%8], %0 offset:3072\n\tds_read_b128 a[%9:%10], %0 offset:4096\n\tds_read_b128 a[%11:%12], %0 offset:5120\n\t"
+                     "ds_read_b128 a[%13:%14], %0 offset:6144\n\tds_read_b128 a[%15:%16], %0 offset:7168\n\ts_waitcnt lgkmcnt(0)" ::"v"(la),
+                     "n"(R0), "n"(R0 + 3), "n"(R0 + 4), "n"(R0 + 7), "n"(R0 + 8), "n"(R0 + 11), "n"(R0 + 12), "n"(R0 + 15), "n"(R0 + 16),
+                     "n"(R0 + 19), "n"(R0 + 20), "n"(R0 + 23), "n"(R0 + 24), "n"(R0 + 27), "n"(R0 + 28), "n"(R0 + 31)
+                     : "memory", IFL_AGPRS);
+    else
+        asm volatile("ds_read_b128 a[%1:%2], %0\n\tds_read_b128 a[%3:%4], %0 offset:1024\n\tds_read_b128 a[%5:%6], %0 offset:2048\n\t"
+                     "ds_read_b128 a[%7:%8], %0 offset:3072\n\ts_waitcnt lgkmcnt(0)" ::"v"(la),
+                     "n"(R0), "n"(R0 + 3), "n"(R0 + 4), "n"(R0 + 7), "n"(R0 + 8), "n"(R0 + 11), "n"(R0 + 12), "n"(R0 + 15)
+                     : "memory", IFL_AGPRS);
+}
+// the lanes m of the buffer -> LDS, register i at la + 128 i (8 channels per instruction: a row of 32 pixels)
+template <int R0, int NIM> __device__ __forceinline__ void rb_write_all(unsigned long long m, unsigned la)
+{
+    unsigned long long sv;
+    if constexpr (NIM == 8)
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\t"
+                     "ds_write_b128 %2, a[%3:%4]\n\tds_write_b128 %2, a[%5:%6] offset:128\n\tds_write_b128 %2, a[%7:%8] offset:256\n\t"
+                     "ds_write_b128 %2, a[%9:%10] offset:384\n\tds_write_b128 %2, a[%11:%12] offset:512\n\tds_write_b128 %2, a[%13:%14] offset:640\n\t"
+                     "ds_write_b128 %2, a[%15:%16] offset:768\n\tds_write_b128 %2, a[%17:%18] offset:896\n\ts_mov_b64 exec, %0"
+                     : "=&s"(sv)
+                     : "s"(m), "v"(la), "n"(R0), "n"(R0 + 3), "n"(R0 + 4), "n"(R0 + 7), "n"(R0 + 8), "n"(R0 + 11), "n"(R0 + 12), "n"(R0 + 15),
+                       "n"(R0 + 16), "n"(R0 + 19), "n"(R0 + 20), "n"(R0 + 23), "n"(R0 + 24), "n"(R0 + 27), "n"(R0 + 28), "n"(R0 + 31)
+                     : "memory", IFL_AGPRS);
+    else
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\t"
+                     "ds_write_b128 %2, a[%3:%4]\n\tds_write_b128 %2, a[%5:%6] offset:128\n\tds_write_b128 %2, a[%7:%8] offset:256\n\t"
+                     "ds_write_b128 %2, a[%9:%10] offset:384\n\ts_mov_b64 exec, %0"
+                     : "=&s"(sv)
+                     : "s"(m), "v"(la), "n"(R0), "n"(R0 + 3), "n"(R0 + 4), "n"(R0 + 7), "n"(R0 + 8), "n"(R0 + 11), "n"(R0 + 12), "n"(R0 + 15)
+                     : "memory", IFL_AGPRS);
+}
+// ... and back: LDS -> the lanes m of the buffer (asynchronous: s_waitcnt lgkmcnt before the registers are used)
+template <int R0, int NIM> __device__ __forceinline__ void rb_read_all(unsigned long long m, unsigned la)
+{
+    unsigned long long sv;
+    if constexpr (NIM == 8)
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\t"
+                     "ds_read_b128 a[%3:%4], %2\n\tds_read_b128 a[%5:%6], %2 offset:128\n\tds_read_b128 a[%7:%8], %2 offset:256\n\t"
+                     "ds_read_b128 a[%9:%10], %2 offset:384\n\tds_read_b128 a[%11:%12], %2 offset:512\n\tds_read_b128 a[%13:%14], %2 offset:640\n\t"
+                     "ds_read_b128 a[%15:%16], %2 offset:768\n\tds_read_b128 a[%17:%18], %2 offset:896\n\ts_mov_b64 exec, %0"
+                     : "=&s"(sv)
+                     : "s"(m), "v"(la), "n"(R0), "n"(R0 + 3), "n"(R0 + 4), "n"(R0 + 7), "n"(R0 + 8), "n"(R0 + 11), "n"(R0 + 12), "n"(R0 + 15),
+                       "n"(R0 + 16), "n"(R0 + 19), "n"(R0 + 20), "n"(R0 + 23), "n"(R0 + 24), "n"(R0 + 27), "n"(R0 + 28), "n"(R0 + 31)
+                     : "memory", IFL_AGPRS);
+    else
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\t"
+                     "ds_read_b128 a[%3:%4], %2\n\tds_read_b128 a[%5:%6], %2 offset:128\n\tds_read_b128 a[%7:%8], %2 offset:256\n\t"
+                     "ds_read_b128 a[%9:%10], %2 offset:384\n\ts_mov_b64 exec, %0"
+                     : "=&s"(sv)
+                     : "s"(m), "v"(la), "n"(R0), "n"(R0 + 3), "n"(R0 + 4), "n"(R0 + 7), "n"(R0 + 8), "n"(R0 + 11), "n"(R0 + 12), "n"(R0 + 15)
+                     : "memory", IFL_AGPRS);
+}
+// one register of a buffer under a lane mask: -> LDS, <- LDS (asynchronous), -> global memory
+template <int R0> __device__ __forceinline__ void rb_write_one(unsigned long long m, unsigned la)
+{
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b128 %2, a[%3:%4]\n\ts_mov_b64 exec, %0"
+                 : "=&s"(sv)
+                 : "s"(m), "v"(la), "n"(R0), "n"(R0 + 3)
+                 : "memory", IFL_AGPRS);
+}
+template <int R0> __device__ __forceinline__ void rb_read_one(unsigned long long m, unsigned la)
+{
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_read_b128 a[%3:%4], %2\n\ts_mov_b64 exec, %0"
+                 : "=&s"(sv)
+                 : "s"(m), "v"(la), "n"(R0), "n"(R0 + 3)
+                 : "memory", IFL_AGPRS);
+}
+template <int R0> __device__ __forceinline__ void rb_store_one(unsigned long long m, unsigned go, char *dst)
+{
+    // (s_nop 4: a scalar register written by a vector instruction -- a spill reload -- is read 5 states late by a
+    // vector-memory instruction, and nobody inserts wait states in front of an asm statement)
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\ts_nop 4\n\tglobal_store_dwordx4 %2, a[%4:%5], %3 " IFL_STR(IFL_ST_POLICY) "\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(sv)
+                 : "s"(m), "v"(go), "s"(dst), "n"(R0), "n"(R0 + 3)
+                 : "memory", IFL_AGPRS);
+}
+
 template <int C, int KH, int KW, bool PAD>
 __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__restrict__ xin, float *__restrict__ zout,
                                                              const half8 *__restrict__ apack, const int H, const int W,
@@ -120,7 +214,7 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                                                              unsigned *__restrict__ amax, const SplitState sp, const int nparts)
 {
     using Cfg = DuoCfg<C, KH, KW>;
-    constexpr int NW = Cfg::NW, NQ = Cfg::NQ, NS = Cfg::NS, RBB = Cfg::RBB, SLOTB = Cfg::SLOTB, G = Cfg::G;
+    constexpr int NW = Cfg::NW, NQ = Cfg::NQ, NS = Cfg::NS, RBB = Cfg::RBB, SLOTB = Cfg::SLOTB;
     constexpr int PF = Cfg::PF, PFH = Cfg::PFH, NXS = Cfg::NXS;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -449,89 +543,38 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
             for (int hl = 0; hl < 2; ++hl) asm volatile("" : "+v"(Z[q][hl]));
         const unsigned fadr = ldsbase + RBB + g * 256 + n * 16; // this lane's B piece of the tile's row n (slot 0)
         const unsigned zadr = ldsbase + Cfg::OFF_ZQ + n * Cfg::ZROWB + c0 * 16;
-        // row operations: lane = channel
-        const bool lane_on = lane < Cr;
-        const int cl = lane_on ? lane : 0;
-        const unsigned voff = (unsigned)((size_t)cl * H * W * sizeof(float));
+        // ---- x and z of this wave's image rows live in REGISTERS, one full 128-byte line per (channel, row) ------------
+        // Tile row r belongs to helper r % NW, as buffer k = r / NW of NIM 16-byte registers per lane.  A row is fetched
+        // whole, by NI = C / CPI LDS-DMA instructions in which NQL = W/4 consecutive lanes cover one (channel, row) line:
+        // every request is a full line, fetched once (lane = channel x quad of the line; the round-1 kernel asked for 16
+        // bytes of a line every fourth step and the L2 had lost the line by then: 5.6 x the algorithmic fetch, and its
+        // partial-line stores were the most expensive thing in the kernel).  The DMA lands in a bounce buffer in LDS (one row
+        // per helper), and just before the row's first pixel is due the helper copies it into its registers.  From then on,
+        // every fourth step, the lanes that hold the row's next quad write it to the x staging, PFX steps before the chain
+        // waves need it; PFX + 7 steps later the same lanes and registers receive the finished z quad from the z staging,
+        // and when the last quad is in, the row goes out as whole lines.  No partial line ever moves.
+        // Nothing asynchronous ever targets these registers (the DMA has no register destination, the LDS reads that fill
+        // them wait inside their own asm statement): the compiler may move the buffers around as it likes.
+        constexpr int RPH = 16 / NW, NIM = C / 8, PFX = 2;
+        const int NQL = W >> 2;                 // quads per image row (<= 8: W <= 32)
+        const int CPI = 64 / NQL;               // channels per instruction
+        const int NI = (Cr + CPI - 1) / CPI;    // instructions per row (<= NIM)
+        const int lq = lane % NQL, lc = lane / NQL; // this lane's quad of the line and channel within the instruction
+        // number of instructions in which this lane carries a channel of the layer (0 for idle lanes)
+        const int imax = lc < CPI ? (Cr - lc + CPI - 1) / CPI : 0;
+        const unsigned goff0 = (unsigned)(lc * H * W * 4 + lq * 16); // byte offset inside an image: channel lc, quad lq
+        const unsigned gstep = (unsigned)(CPI * H * W * 4);          // ... per instruction
         const char *xg = (const char *)xin + (size_t)b * Cr * H * W * sizeof(float);
         char *zg = (char *)zout + (size_t)b * Cr * H * W * sizeof(float);
-        const int grow = rh ? -4 * W : 4 * W, gcol = rw ? -4 : 4;
         const unsigned dmy = __builtin_amdgcn_readfirstlane(ldsbase + Cfg::OFF_DMY + wv * 1024);
         // mailbox role of helper 0: lane l carries the 8-byte piece (row 14 + (l & 1), plane (l >> 1) & 15, half l >> 5)
         const int mrow = 14 + (lane & 1), mpl = (lane >> 1) & 15, mhalf = lane >> 5;
         const bool mlane = mpl < Cfg::NPL;
         const unsigned madr = ldsbase + (mlane ? mpl : 0) * 256 + mrow * 16 + mhalf * 8; // (+ slot, + RBB for the tile's own rows)
+        const bool w_mbox = wv == 0;
 
 #ifdef IFL_STAMPS
         unsigned long long st_slow = 0, st_spins = 0, st_gate = 0, st_h[7] = {0, 0, 0, 0, 0, 0, 0}, st_hl = __builtin_amdgcn_s_memtime();
-#endif
-        auto dma = [&](const char *src, unsigned dst) {
-            // LDS-DMA of one 16-byte quad per lane (lane c lands at dst + 16 c), padded lanes masked off
-            unsigned long long saved;
-            asm volatile("s_mov_b32 m0, %1\n\t"
-                         "s_mov_b64 %0, exec\n\t"
-                         "s_and_b64 exec, exec, %2\n\t"
-                         "global_load_lds_dwordx4 %3, %4 " IFL_STR(IFL_LD_POLICY) "\n\t"
-                         "s_mov_b64 exec, %0"
-                         : "=&s"(saved)
-                         : "s"(dst), "s"(__builtin_amdgcn_ballot_w64(lane_on)), "v"(voff), "s"(src)
-                         : "memory", "scc", "m0");
-        };
-
-        // Jobs of the helper waves besides their z product (each kind of vector-memory traffic has its own wave, so that
-        // a wait on the in-order vmcnt never queues behind another kind: mailbox lines come from far away, stores retire
-        // slowly, x quads must be there on time):
-        //   C = 64: helper 0 mailbox, helpers 1 and 2 the x DMAs (2 rows each per step), helper 3 the z stores (4 rows)
-        //   C = 32: helper 0 mailbox + z stores, helper 1 the x DMAs (4 rows)
-        constexpr int NDW = NW == 4 ? 2 : 1, RD = 4 / NDW;
-        const bool w_mbox = wv == 0;
-        const bool w_dma = NW == 4 ? (wv == 1 || wv == 2) : wv == 1;
-        const bool w_store = NW == 4 ? wv == 3 : wv == 0;
-        const int jd0 = NW == 4 ? RD * (wv - 1) : 0; // first row class of a DMA wave
-
-        auto helper_sweep = [&](const int hoff, const int Hp, const float zscale, const bool publish, const bool consume,
-                                const unsigned tag) {
-            const int ND = Hp + W - 1;
-            const int gbase = (rh ? (H - 1) * 4 * W : 0) + (rw ? (W - 4) * 4 : 0) + hoff * grow;
-            const int u_last = W + 14;  // last upper diagonal with a pixel in row 15
-            const int dl_last = W - 2;  // ... as a diagonal of the lower tile
-            const bool mbox = w_mbox && (publish || consume) && !(IFL_EXP & 8);
-
-            auto poll_line = [&](const int u, uintx4 &q) {
-                // the line prefetched PFH steps ago was not complete: poll it (bounded) with agent-scope loads
-                const unsigned long long *hp = (const unsigned long long *)(mb + (size_t)u * DUO_LINEB + lane * 16);
-#ifdef IFL_STAMPS
-                st_slow += 1;
-#endif
-                for (int spins = 0;; ++spins) {
-#ifdef IFL_STAMPS
-                    st_spins += 1;
-#endif
-                    const unsigned long long a0 = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned long long a1 = __hip_atomic_load(hp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    q = uintx4{(unsigned)a0, (unsigned)(a0 >> 32), (unsigned)a1, (unsigned)(a1 >> 32)};
-                    if (__all(q[1] == tag && q[3] == tag)) return;
-                    if (spins > 20000) { // ~tens of ms: the image is void and redone whole
-                        dead = 1;
-                        return;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-            };
-            if (consume && mbox) {
-                // gate: start once the upper part's diagonal 14 + GATE is visible, so that every prefetch finds its line
-                uintx4 q;
-#ifdef IFL_STAMPS
-                const unsigned long long g0 = __builtin_amdgcn_s_memrealtime();
-#endif
-                poll_line(14 + Cfg::GATE < u_last ? 14 + Cfg::GATE : u_last, q);
-#ifdef IFL_STAMPS
-                st_gate = __builtin_amdgcn_s_memrealtime() - g0;
-                st_slow = 0;
-#endif
-            }
-
-#ifdef IFL_STAMPS
 #define IFL_HSTAMP(k)                                                  \
     do {                                                               \
         const unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
@@ -543,194 +586,27 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
     do {              \
     } while (0)
 #endif
-            auto step = [&](const int d) {
-                IFL_HSTAMP(6); // (the wait at the end of the previous step)
-                asm volatile("s_barrier" ::: "memory");
-                IFL_HSTAMP(0); // barrier
-                // ---- every LDS request of the step first, one wait for all of them ----------------------------------------
-                const bool h_in = consume && mbox && d >= -2 && d <= dl_last && !dead;
-                const bool h_out = publish && mbox && d - 1 >= 14 && d - 1 <= u_last;
-                const bool zprod = d >= 1 && d <= ND && !(IFL_EXP & 4);
-                floatx4_ hq;
-                if (h_in) {
-                    // (younger than that line's DMA: the prefetches of PFH - 1 steps; with C = 32 also this wave's stores)
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PFH - 1) : "memory");
-                    lds_read_f32x4(hq, ldsbase + Cfg::OFF_HALO + (d & (Cfg::NHL - 1)) * 1024 + lane * 16);
-                }
-                half8 Fh[NQ], Fl[NQ];
-                if (zprod) {
-                    const unsigned fa = fadr + ((d + 1) & 1) * SLOTB;
-                    lds_read_b128_o<0>(Fh[0], fa);
-                    lds_read_b128_o<4 * 256>(Fl[0], fa);
-                    if constexpr (NQ == 2) {
-                        lds_read_b128_o<8 * 256>(Fh[1], fa);
-                        lds_read_b128_o<12 * 256>(Fl[1], fa);
-                    }
-                }
-                // store role: rows h = d-1 (mod 4) completed a quad of z with diagonal d-2 (staged one step ago)
-                floatx4_ sv[4];
-                bool sok[4];
-                if (w_store) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int hr = ((d - 1) & 3) + 4 * j;
-                        const int wq = d - 5 - hr;
-                        sok[j] = hr < Hp && wq >= 0 && wq < W; // (wave-uniform)
-                        if (sok[j])
-                            lds_read_f32x4(sv[j], ldsbase + Cfg::OFF_ZQ + hr * Cfg::ZROWB + ((wq >> 2) & 1) * (C * 16) + cl * 16);
-                    }
-                }
-                uintx2 pv;
-                if (h_out)
-                    asm volatile("ds_read_b64 %0, %1" : "=v"(pv) : "v"(madr + RBB + ((d - 1) & 1) * SLOTB) : "memory");
-                IFL_HSTAMP(1); // requests
-                // ---- vector-memory requests that need no data: the x quads first used PF steps from now (unconditional:
-                //      exact operation count), the mailbox line to be delivered PFH steps from now
-                if (w_dma && !(IFL_EXP & 1)) {
-#pragma unroll
-                    for (int i = 0; i < RD; ++i) {
-                        const int hr = ((d + PF) & 3) + 4 * (jd0 + i);
-                        const int wq = d + PF - hr;
-                        const bool ok = hr < Hp && wq >= 0 && wq < W;
-                        const char *src = xg + (ok ? gbase + hr * grow + wq * gcol : 0);
-                        const unsigned dst = ok ? ldsbase + Cfg::OFF_XS + hr * Cfg::XROWB + ((wq >> 2) & (NXS - 1)) * (C * 16) : dmy;
-                        dma(src, __builtin_amdgcn_readfirstlane(dst));
-                    }
-                }
-                if (consume && mbox) {
-                    const int dl = d + PFH;
-                    const bool ok = dl >= -2 && dl <= dl_last;
-                    const char *line = mb + (size_t)(ok ? dl + 16 : 0) * DUO_LINEB;
-                    const unsigned dst = __builtin_amdgcn_readfirstlane(ok ? ldsbase + Cfg::OFF_HALO + (dl & (Cfg::NHL - 1)) * 1024 : dmy);
-                    asm volatile("s_mov_b32 m0, %0\n\t"
-                                 "global_load_lds_dwordx4 %1, %2 sc0 sc1" ::"s"(dst), "v"(lane * 16), "s"(line)
-                                 : "memory", "m0");
-                }
-                IFL_HSTAMP(2); // dma issue
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                IFL_HSTAMP(3); // LDS wait
-                // ---- hand-off in: rows 14, 15 of the upper part's diagonal d + 16 join diagonal d of this tile's ring
-                if (h_in) {
-                    asm volatile("" : "+v"(hq));
-                    uintx4 q = __builtin_bit_cast(uintx4, hq);
-                    if (!__all(q[1] == tag && q[3] == tag)) poll_line(d + 16, q);
-                    if (mlane && !dead) {
-                        const uintx2 v = {q[0], q[2]};
-                        asm volatile("ds_write_b64 %0, %1" ::"v"(madr + (d & 1) * SLOTB), "v"(v) : "memory");
-                    }
-                }
-                // ---- z of diagonal d-1 = L^-1 r_{d-1}: this wave's six MFMAs go ahead of the chain wave's (they are few)
-                floatx4 zh, zm;
-                if (zprod) {
-                    if constexpr (NQ == 2)
-                        asm volatile("s_setprio " IFL_STR(IFL_PRIO_ZPROD) : "+v"(Fh[0]), "+v"(Fl[0]), "+v"(Fh[1]), "+v"(Fl[1]));
-                    else
-                        asm volatile("s_setprio " IFL_STR(IFL_PRIO_ZPROD) : "+v"(Fh[0]), "+v"(Fl[0]));
-                    const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        zh = __builtin_amdgcn_mfma_f32_16x16x32_f16(Z[q][0], Fh[q], q ? zh : zero, 0, 0, 0);
-                        zm = __builtin_amdgcn_mfma_f32_16x16x32_f16(Z[q][0], Fl[q], q ? zm : zero, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) zm = __builtin_amdgcn_mfma_f32_16x16x32_f16(Z[q][1], Fh[q], zm, 0, 0, 0);
-                    asm volatile("s_setprio " IFL_STR(IFL_PRIO_HELPER) : "+v"(zh), "+v"(zm));
-                }
-                IFL_HSTAMP(4); // hand-off in + z product
-                // ---- stores: finished z quads, the mailbox line of the diagonal the chain waves finished in the previous step
-                if (w_store) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (sok[j]) {
-                            const int hr = ((d - 1) & 3) + 4 * j;
-                            const int wq = d - 5 - hr;
-                            char *dst = zg + (gbase + hr * grow + wq * gcol);
-                            if (lane_on && !(IFL_EXP & 2)) {
-                                // (s_nop: a store of more than 8 bytes reads its data registers a cycle late; the maximum below rewrites them)
-                                asm volatile("global_store_dwordx4 %0, %1, %2 " IFL_STR(IFL_ST_POLICY) "\n\ts_nop 1" ::"v"(voff), "v"(sv[j]), "s"(dst) : "memory");
-                            }
-                        }
-                }
-                if (h_out) {
-                    const int u = d - 1;
-                    // (zero outside the image: the operator's padding; the ring keeps older pixels there)
-                    const bool in = mlane && (unsigned)(u - mrow) < (unsigned)W;
-                    const uintx4 q = {in ? pv[0] : 0u, tag, in ? pv[1] : 0u, tag};
-                    char *line = mb + (size_t)u * DUO_LINEB;
-                    asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(lane * 16), "v"(q), "s"(line) : "memory");
-                }
-                // ---- z -> staging, at that column's in-row offset (columns outside the image land in quads that are not
-                //      live: before a row's first quad, or in the parity its last one does not use)
-                if (zprod) {
-                    const int wz = d - 1 - n;
-                    const unsigned za = zadr + ((wz >> 2) & 1) * (C * 16) + (rw ? 3 - (wz & 3) : (wz & 3)) * 4;
-                    float zv[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        zv[r] = (zh[r] + zm[r] * LO_INV) * zscale;
-                        asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(za), "v"(zv[r]), "n"(r * 16) : "memory");
-                    }
-                    // max |z| from the staged values: a column outside the image repeats an older pixel of its row (the ring
-                    // keeps it) or is zero, so the maximum over everything staged is the maximum over the image
-                    zmax = fmaxf(fmaxf(zmax, fabsf(zv[0])), fmaxf(fabsf(zv[1]), fmaxf(fabsf(zv[2]), fabsf(zv[3]))));
-                }
-                IFL_HSTAMP(5); // stores + staging
-                // the x quads of the next step have landed (younger: the DMAs of PF-1 steps), LDS writes drained
-                if (w_dma) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * RD) : "memory");
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            };
-            for (int d = -PF; d <= ND + 1; ++d) step(d);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // "all but the n youngest vector-memory operations are complete" for a run-time n (an immediate in the instruction)
+        auto wait_vm = [&](int n) {
+#define IFL_V(N) \
+    case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+            switch (n < 0 ? 0 : n) {
+                IFL_V(0) IFL_V(1) IFL_V(2) IFL_V(3) IFL_V(4) IFL_V(5) IFL_V(6) IFL_V(7) IFL_V(8) IFL_V(9) IFL_V(10) IFL_V(11)
+                IFL_V(12) IFL_V(13) IFL_V(14) IFL_V(15) IFL_V(16) IFL_V(17) IFL_V(18) IFL_V(19) IFL_V(20) IFL_V(21) IFL_V(22)
+                IFL_V(23) IFL_V(24) IFL_V(25) IFL_V(26) IFL_V(27) IFL_V(28) IFL_V(29) IFL_V(30) IFL_V(31) IFL_V(32) IFL_V(33)
+                IFL_V(34) IFL_V(35) IFL_V(36) IFL_V(37) IFL_V(38) IFL_V(39) IFL_V(40) IFL_V(41) IFL_V(42) IFL_V(43) IFL_V(44)
+                IFL_V(45) IFL_V(46) IFL_V(47) IFL_V(48) IFL_V(49) IFL_V(50) IFL_V(51) IFL_V(52) IFL_V(53) IFL_V(54) IFL_V(55)
+                IFL_V(56)
+            default: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
+            }
+#undef IFL_V
         };
-
         auto reduce_amax = [&]() {
             if (amax) {
                 for (int o = 32; o > 0; o >>= 1) zmax = fmaxf(zmax, __shfl_down(zmax, o, 64));
                 if (lane == 0) atomicMax(amax, __float_as_uint(zmax)); // one atomic per wave; max is order-independent
             }
         };
-
-        __syncthreads();
-        asm volatile("s_setprio " IFL_STR(IFL_PRIO_HELPER));
-        const unsigned tag1 = gen0 + 1, tag2 = gen0 + 2;
-        helper_sweep(my_part == 1 ? 16 : 0, my_part == 1 ? H - 16 : (H < 16 ? H : 16), 1.0f, my_part == 0, my_part == 1, tag1);
-#ifdef IFL_STAMPS
-        if (g_stamps && b == 0 && tid == NW * 64) {
-            unsigned long long *o = g_stamps + (my_part == 1 ? 32 : 0);
-            o[8] = st_slow, o[9] = st_spins, o[10] = st_gate;
-            for (int k = 0; k < 7; ++k) o[16 + k] = st_h[k];
-        }
-#endif
-        int bad = __syncthreads_or(dead << 1);
-        if (my_part == 0) {
-            // The verdict tells the lower part whether this tile is good.  If not, this L2's dirty lines of z go back first
-            // (agent-scope release), so that they cannot land on top of the redone rows later (the two workgroups may sit
-            // on XCDs with separate L2s).
-            if (!bad) reduce_amax();
-            if (tid == NW * 64) {
-                if (bad) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                __hip_atomic_store(verdict, ((unsigned long long)tag1 << 32) | (unsigned)(bad ? 2 : 1), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            }
-            return;
-        }
-        if (my_part == 1) {
-            // (the upper part finished some twenty steps ago: one poll in practice; bounded all the same)
-            unsigned pv = 0;
-            for (int spins = 0; spins < 20000; ++spins) {
-                const unsigned long long v = __hip_atomic_load(verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned)(v >> 32) == tag1) {
-                    pv = (unsigned)v;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            bad = __syncthreads_or(bad | (pv == 1 ? 0 : 1)); // (no verdict in time counts as a failed hand-off)
-        }
-        if (IFL_EXP) bad = 0;
         // the next launch uses other tags (both parts have read this one long ago).  Close to the wrap the image's lines
         // are cleaned, so that a tag of 2^31 launches ago cannot pass for a fresh one.
         auto advance_generation = [&]() {
@@ -742,28 +618,405 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
             }
             if (tid == NW * 64) sp.gen[b] = gen0 >= 0xFFFFFFF0u ? 0u : gen0 + 2;
         };
-        if (!bad) {
-            reduce_amax();
-            if (tid == NW * 64) flags[b] = 0;
-            advance_generation();
-            return;
-        }
-        // redo (see the chain waves): scaled sweeps of both tiles through the mailbox, under the second tag
-        zmax = 0.f;
-        dead = 0;
+
+        __syncthreads();
+        asm volatile("s_setprio " IFL_STR(IFL_PRIO_HELPER));
+        const unsigned tag1 = gen0 + 1, tag2 = gen0 + 2;
         const int ntile = split ? 2 : 1;
-        for (int t = 0; t < ntile; ++t) {
-            zero_ring();
-            __syncthreads();
-            helper_sweep(t ? 16 : 0, split ? (t ? H - 16 : 16) : H, 4096.0f, split && t == 0, split && t == 1, tag2);
-            __syncthreads();
+        // pass 0: the tile this workgroup was launched for; passes 1, 2: the redo of the whole image (see the chain waves)
+        for (int pass = 0; pass < 3; ++pass) {
+            int hoff, Hp;
+            float zscale;
+            bool publish, consume;
+            unsigned tag;
+            if (pass == 0) {
+                hoff = my_part == 1 ? 16 : 0;
+                Hp = my_part == 1 ? H - 16 : (H < 16 ? H : 16);
+                zscale = 1.0f;
+                publish = my_part == 0;
+                consume = my_part == 1;
+                tag = tag1;
+            } else {
+                const int t = pass - 1;
+                if (t >= ntile) break;
+                zero_ring();
+                __syncthreads();
+                hoff = t ? 16 : 0;
+                Hp = split ? (t ? H - 16 : 16) : H;
+                zscale = 4096.0f;
+                publish = split && t == 0;
+                consume = split && t == 1;
+                tag = tag2;
+            }
+            // ================================ one sweep over the tile ==================================================
+            {
+                const int ND = Hp + W - 1;
+                const int u_last = W + 14;  // last upper diagonal with a pixel in row 15
+                const int dl_last = W - 2;  // ... as a diagonal of the lower tile
+                const bool mbox = w_mbox && (publish || consume) && !(IFL_EXP & 8);
+                // byte offset of tile row r inside a channel plane (rows may be reflected)
+                auto row_off = [&](int r) { return (rh ? H - 1 - (hoff + r) : hoff + r) * W * 4; };
+
+                auto poll_line = [&](const int u, uintx4 &q) {
+                    // the line prefetched PFH steps ago was not complete: poll it (bounded) with agent-scope loads
+                    const unsigned long long *hp = (const unsigned long long *)(mb + (size_t)u * DUO_LINEB + lane * 16);
+#ifdef IFL_STAMPS
+                    st_slow += 1;
+#endif
+                    for (int spins = 0;; ++spins) {
+#ifdef IFL_STAMPS
+                        st_spins += 1;
+#endif
+                        const unsigned long long a0 = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long a1 = __hip_atomic_load(hp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        q = uintx4{(unsigned)a0, (unsigned)(a0 >> 32), (unsigned)a1, (unsigned)(a1 >> 32)};
+                        if (__all(q[1] == tag && q[3] == tag)) return;
+                        if (spins > 20000) { // ~tens of ms: the image is void and redone whole
+                            dead = 1;
+                            return;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                };
+
+                // masks of the lanes that carry data (all instructions but the row's last / the last one: a layer whose
+                // channel count is no multiple of CPI ends inside it), and the same restricted to one quad of the line
+                const unsigned long long m_all = __builtin_amdgcn_ballot_w64(lc < CPI);
+                const unsigned long long m_end = __builtin_amdgcn_ballot_w64(NI - 1 < imax);
+                const bool plain = NI == NIM && m_end == m_all; // every instruction of a row is alike (no padded channels)
+                const unsigned bnc = __builtin_amdgcn_readfirstlane(ldsbase + Cfg::OFF_BNC + wv * (NIM * 1024));
+
+                // row r -> bounce buffer (LDS-DMA, whole lines)
+                auto row_fetch = [&](const int r) {
+                    if (r >= Hp || (IFL_EXP & 1)) return;
+                    const char *src = xg + row_off(r);
+#pragma unroll
+                    for (int i = 0; i < NIM; ++i)
+                        if (i < NI) { // (wave-uniform: every instruction issued has a lane: exact operation count)
+                            const unsigned long long m = i == NI - 1 ? m_end : m_all;
+                            const unsigned go = goff0 + i * gstep;
+                            const unsigned dst = bnc + i * 1024;
+                            unsigned long long sv;
+                            asm volatile("s_mov_b32 m0, %1\n\t"
+                                         "s_mov_b64 %0, exec\n\t"
+                                         "s_mov_b64 exec, %2\n\t"
+                                         "s_nop 4\n\t" // (a scalar register written by a vector instruction -- a spill reload -- is read 5 states late)
+                                         "global_load_lds_dwordx4 %3, %4\n\t"
+                                         "s_mov_b64 exec, %0"
+                                         : "=&s"(sv)
+                                         : "s"(dst), "s"(m), "v"(go), "s"(src)
+                                         : "memory", "m0");
+                        }
+                };
+                // bounce buffer -> buffer K (complete on return)
+                auto row_take = [&](auto k_c) {
+                    constexpr int K = decltype(k_c)::value;
+                    rb_take<4 * K * NIM, NIM>(bnc + lane * 16);
+                };
+                // quad ql of row r (buffer K) -> x staging [row][ql & 1][channel][4]
+                auto row_x = [&](auto k_c, const int r, const int ql) {
+                    constexpr int K = decltype(k_c)::value;
+                    const int pq = rw ? NQL - 1 - ql : ql;
+                    const unsigned la = ldsbase + Cfg::OFF_XS + r * Cfg::XROWB + (ql & 1) * (C * 16) + lc * 16;
+                    const unsigned long long mq = __builtin_amdgcn_ballot_w64(lq == pq && lc < CPI);
+                    if (plain && CPI == 8) {
+                        rb_write_all<4 * K * NIM, NIM>(mq, la);
+                    } else {
+                        auto one = [&](auto i_c) {
+                            constexpr int I = decltype(i_c)::value;
+                            if (I < NI) rb_write_one<4 * (K * NIM + I)>(mq & (I == NI - 1 ? m_end : m_all), la + I * CPI * 16);
+                        };
+                        one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
+                        one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
+                        if constexpr (NIM == 8) {
+                            one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
+                            one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
+                        }
+                    }
+                };
+                // finished z quad ql of row r (staged through the previous step) -> the registers its x came from
+                // (asynchronous: the end-of-step wait covers it)
+                auto row_z = [&](auto k_c, const int r, const int ql) {
+                    constexpr int K = decltype(k_c)::value;
+                    const int pq = rw ? NQL - 1 - ql : ql;
+                    const unsigned la = ldsbase + Cfg::OFF_ZQ + r * Cfg::ZROWB + (ql & 1) * (C * 16) + lc * 16;
+                    const unsigned long long mq = __builtin_amdgcn_ballot_w64(lq == pq && lc < CPI);
+                    if (plain && CPI == 8) {
+                        rb_read_all<4 * K * NIM, NIM>(mq, la);
+                    } else {
+                        auto one = [&](auto i_c) {
+                            constexpr int I = decltype(i_c)::value;
+                            if (I < NI) rb_read_one<4 * (K * NIM + I)>(mq & (I == NI - 1 ? m_end : m_all), la + I * CPI * 16);
+                        };
+                        one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
+                        one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
+                        if constexpr (NIM == 8) {
+                            one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
+                            one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
+                        }
+                    }
+                };
+                auto row_out = [&](auto k_c, const int r) {
+                    constexpr int K = decltype(k_c)::value;
+                    {
+                        char *dst = zg + row_off(r);
+                        auto one = [&](auto i_c) {
+                            constexpr int I = decltype(i_c)::value;
+                            if (I < NI) rb_store_one<4 * (K * NIM + I)>(I == NI - 1 ? m_end : m_all, goff0 + I * gstep, dst);
+                        };
+                        one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
+                        one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
+                        if constexpr (NIM == 8) {
+                            one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
+                            one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
+                        }
+                    }
+                };
+                // the rows r = c + 4 j of this wave, with their buffers (compile-time): op(K, r)
+                auto for_rows = [&](const int c, auto &&op) {
+                    if constexpr (NW == 4) {
+                        op(std::integral_constant<int, 0>{}, c);
+                        op(std::integral_constant<int, 1>{}, c + 4);
+                        op(std::integral_constant<int, 2>{}, c + 8);
+                        op(std::integral_constant<int, 3>{}, c + 12);
+                    } else if (c < 2) {
+                        op(std::integral_constant<int, 0>{}, c);
+                        op(std::integral_constant<int, 2>{}, c + 4);
+                        op(std::integral_constant<int, 4>{}, c + 8);
+                        op(std::integral_constant<int, 6>{}, c + 12);
+                    } else {
+                        op(std::integral_constant<int, 1>{}, c);
+                        op(std::integral_constant<int, 3>{}, c + 4);
+                        op(std::integral_constant<int, 5>{}, c + 8);
+                        op(std::integral_constant<int, 7>{}, c + 12);
+                    }
+                };
+
+                if (consume && mbox) {
+                    // gate: start once the upper part's diagonal 14 + GATE is visible, so that every prefetch finds its line
+                    uintx4 q;
+#ifdef IFL_STAMPS
+                    const unsigned long long g0 = __builtin_amdgcn_s_memrealtime();
+#endif
+                    poll_line(14 + Cfg::GATE < u_last ? 14 + Cfg::GATE : u_last, q);
+#ifdef IFL_STAMPS
+                    st_gate = __builtin_amdgcn_s_memrealtime() - g0;
+                    st_slow = 0;
+#endif
+                }
+                // this wave's first row is on its way before the first step
+                row_fetch(wv);
+
+                auto step = [&](const int d) {
+                    IFL_HSTAMP(6); // (the wait at the end of the previous step)
+                    asm volatile("s_barrier" ::: "memory");
+                    IFL_HSTAMP(0); // barrier
+                    const bool h_in = consume && mbox && d >= -2 && d <= dl_last && !dead;
+                    const bool h_out = publish && mbox && d - 1 >= 14 && d - 1 <= u_last;
+                    const bool zprod = d >= 1 && d <= ND && !(IFL_EXP & 4);
+                    // ---- LDS requests whose data the step needs: the mailbox line that landed, the fragments of r_{d-1}
+                    floatx4_ hq;
+                    if (h_in) {
+                        // (younger than that line's DMA: the prefetches of PFH - 1 steps)
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PFH - 1) : "memory");
+                        lds_read_f32x4(hq, ldsbase + Cfg::OFF_HALO + (d & (Cfg::NHL - 1)) * 1024 + lane * 16);
+                    }
+                    half8 Fh[NQ], Fl[NQ];
+                    if (zprod) {
+                        const unsigned fa = fadr + ((d + 1) & 1) * SLOTB;
+                        lds_read_b128_o<0>(Fh[0], fa);
+                        lds_read_b128_o<4 * 256>(Fl[0], fa);
+                        if constexpr (NQ == 2) {
+                            lds_read_b128_o<8 * 256>(Fh[1], fa);
+                            lds_read_b128_o<12 * 256>(Fl[1], fa);
+                        }
+                    }
+                    uintx2 pv;
+                    if (h_out)
+                        asm volatile("ds_read_b64 %0, %1" : "=v"(pv) : "v"(madr + RBB + ((d - 1) & 1) * SLOTB) : "memory");
+                    IFL_HSTAMP(1); // requests
+                    // ---- x duty: the rows r = d + PFX (mod 4) start a quad PFX steps from now; they all belong to one helper
+                    {
+                        const int c = (d + PFX) & 3;
+                        if ((c % NW) == wv) {
+                            const int q0 = (d + PFX - c) >> 2; // quad of row c; row c + 4 j is at quad q0 - j
+                            // the row whose first quad this is comes out of the bounce buffer, and the next one goes in
+                            for_rows(c, [&](auto k_c, const int r) {
+                                if (r < Hp && ((d + PFX - r) >> 2) == 0) {
+                                    // its DMA is complete: behind it this wave issued the mailbox operations of the steps since
+                                    // (one per step, mailbox helper only), nothing else
+                                    if (mbox) wait_vm(r < NW ? r + Cfg::PF - PFX : NW);
+                                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                    row_take(k_c);
+                                    row_fetch(r + NW);
+                                }
+                            });
+                            for_rows(c, [&](auto k_c, const int r) {
+                                const int ql = (d + PFX - r) >> 2;
+                                if (r < Hp && ql >= 0 && ql < NQL) row_x(k_c, r, ql);
+                            });
+                            (void)q0;
+                        }
+                    }
+                    // ---- the mailbox helper issues exactly one vector-memory operation per step besides its rows:
+                    //      the line to be delivered PFH steps from now (lower part) ...
+                    if (consume && mbox) {
+                        const int dl = d + PFH;
+                        const bool ok = dl >= -2 && dl <= dl_last;
+                        const char *line = mb + (size_t)(ok ? dl + 16 : 0) * DUO_LINEB;
+                        const unsigned dst = __builtin_amdgcn_readfirstlane(ok ? ldsbase + Cfg::OFF_HALO + (dl & (Cfg::NHL - 1)) * 1024 : dmy);
+                        asm volatile("s_mov_b32 m0, %0\n\t"
+                                     "s_nop 4\n\t"
+                                     "global_load_lds_dwordx4 %1, %2 sc0 sc1" ::"s"(dst), "v"(lane * 16), "s"(line)
+                                     : "memory", "m0");
+                    }
+                    IFL_HSTAMP(2); // x quads
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    IFL_HSTAMP(3); // LDS wait
+                    // ---- hand-off in: rows 14, 15 of the upper part's diagonal d + 16 join diagonal d of this tile's ring
+                    if (h_in) {
+                        asm volatile("" : "+v"(hq));
+                        uintx4 q = __builtin_bit_cast(uintx4, hq);
+                        if (!__all(q[1] == tag && q[3] == tag)) poll_line(d + 16, q);
+                        if (mlane && !dead) {
+                            const uintx2 v = {q[0], q[2]};
+                            asm volatile("ds_write_b64 %0, %1" ::"v"(madr + (d & 1) * SLOTB), "v"(v) : "memory");
+                        }
+                    }
+                    // ---- z of diagonal d-1 = L^-1 r_{d-1}: this wave's six MFMAs go ahead of the chain wave's (they are few)
+                    floatx4 zh, zm;
+                    if (zprod) {
+                        if constexpr (NQ == 2)
+                            asm volatile("s_setprio " IFL_STR(IFL_PRIO_ZPROD) : "+v"(Fh[0]), "+v"(Fl[0]), "+v"(Fh[1]), "+v"(Fl[1]));
+                        else
+                            asm volatile("s_setprio " IFL_STR(IFL_PRIO_ZPROD) : "+v"(Fh[0]), "+v"(Fl[0]));
+                        // (as asm with the accumulators in ordinary registers: with 2 waves per SIMD the row buffers fill the
+                        // accumulator half of the register file.  The first product of each accumulator takes the constant 0:
+                        // a register zeroed by a vector instruction just before would be read too early -- nobody inserts wait
+                        // states around an asm MFMA.  Same products in the same order as the chain wave's z product of
+                        // scan_mfma.hip: bit-identical results.)
+                        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(zh) : "v"(Z[0][0]), "v"(Fh[0]));
+                        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(zm) : "v"(Z[0][0]), "v"(Fl[0]));
+#pragma unroll
+                        for (int q = 1; q < NQ; ++q) {
+                            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(zh) : "v"(Z[q][0]), "v"(Fh[q]));
+                            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(zm) : "v"(Z[q][0]), "v"(Fl[q]));
+                        }
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(zm) : "v"(Z[q][1]), "v"(Fh[q]));
+                        // (the results are read by vector instructions below: the wait states the compiler would insert)
+                        asm volatile("s_setprio " IFL_STR(IFL_PRIO_HELPER) "\n\ts_nop 7\n\ts_nop 7" : "+v"(zh), "+v"(zm));
+                    }
+                    IFL_HSTAMP(4); // hand-off in + z product
+                    // ---- ... or the line of the diagonal the chain waves finished in the previous step (upper part; a spare
+                    //      line takes the steps without one: the operation count stays exact)
+                    if (publish && mbox) {
+                        const int u = d - 1;
+                        // (zero outside the image: the operator's padding; the ring keeps older pixels there)
+                        const bool in = h_out && mlane && (unsigned)(u - mrow) < (unsigned)W;
+                        const uintx4 q = {in ? pv[0] : 0u, tag, in ? pv[1] : 0u, tag};
+                        char *line = mb + (size_t)(h_out ? u : DUO_LINES - 2) * DUO_LINEB;
+                        asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(lane * 16), "v"(q), "s"(line) : "memory");
+                    }
+                    // ---- z duty: the rows r = d - 5 (mod 4) completed a quad of z with diagonal d-2 (staged one step ago)
+                    {
+                        const int c = (d - 5) & 3;
+                        if ((c % NW) == wv) {
+                            bool last = false;
+                            for_rows(c, [&](auto k_c, const int r) {
+                                const int ql = (d - 5 - r) >> 2;
+                                if (r < Hp && ql >= 0 && ql < NQL) {
+                                    row_z(k_c, r, ql);
+                                    last = last || ql == NQL - 1;
+                                }
+                            });
+                            if (last && !(IFL_EXP & 2)) { // a row's last quad: the row goes out as whole lines
+                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                                for_rows(c, [&](auto k_c, const int r) {
+                                    if (r < Hp && ((d - 5 - r) >> 2) == NQL - 1) row_out(k_c, r);
+                                });
+                            }
+                        }
+                    }
+                    // ---- z -> staging, at that column's in-row offset (columns outside the image land in quads that are
+                    //      not live: before a row's first quad, or in the parity its last one does not use)
+                    if (zprod) {
+                        const int wz = d - 1 - n;
+                        const unsigned za = zadr + ((wz >> 2) & 1) * (C * 16) + (rw ? 3 - (wz & 3) : (wz & 3)) * 4;
+                        float zv[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            zv[r] = (zh[r] + zm[r] * LO_INV) * zscale;
+                            asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(za), "v"(zv[r]), "n"(r * 16) : "memory");
+                        }
+                        // max |z| from the staged values: a column outside the image repeats an older pixel of its row (the
+                        // ring keeps it) or is zero, so the maximum over everything staged is the maximum over the image
+                        zmax = fmaxf(fmaxf(zmax, fabsf(zv[0])), fmaxf(fabsf(zv[1]), fmaxf(fabsf(zv[2]), fabsf(zv[3]))));
+                    }
+                    IFL_HSTAMP(5); // z quads + staging
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // x quads and z staged by this wave are in LDS
+                };
+                for (int d = -Cfg::PF; d <= ND + 1; ++d) step(d);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            // ================================ between the sweeps ========================================================
+            if (pass > 0) {
+                __syncthreads();
+                continue;
+            }
+#ifdef IFL_STAMPS
+            if (g_stamps && b == 0 && tid == NW * 64) {
+                unsigned long long *o = g_stamps + (my_part == 1 ? 32 : 0);
+                o[8] = st_slow, o[9] = st_spins, o[10] = st_gate;
+                for (int k = 0; k < 7; ++k) o[16 + k] = st_h[k];
+            }
+#endif
+            int bad = __syncthreads_or(dead << 1);
+            if (my_part == 0) {
+                // The verdict tells the lower part whether this tile is good.  If not, this L2's dirty lines of z go back
+                // first (agent-scope release), so that they cannot land on top of the redone rows later (the two workgroups
+                // may sit on XCDs with separate L2s).
+                if (!bad) reduce_amax();
+                if (tid == NW * 64) {
+                    if (bad) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    __hip_atomic_store(verdict, ((unsigned long long)tag1 << 32) | (unsigned)(bad ? 2 : 1), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+                return;
+            }
+            if (my_part == 1) {
+                // (the upper part finished some twenty steps ago: one poll in practice; bounded all the same)
+                unsigned pv = 0;
+                for (int spins = 0; spins < 20000; ++spins) {
+                    const unsigned long long v = __hip_atomic_load(verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(v >> 32) == tag1) {
+                        pv = (unsigned)v;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                bad = __syncthreads_or(bad | (pv == 1 ? 0 : 1)); // (no verdict in time counts as a failed hand-off)
+            }
+            if (IFL_EXP) bad = 0;
+            if (!bad) {
+                reduce_amax();
+                if (tid == NW * 64) flags[b] = 0;
+                advance_generation();
+                return;
+            }
+            // redo: scaled sweeps of both tiles through the mailbox, under the second tag
+            zmax = 0.f;
+            dead = 0;
         }
         const int bad2 = __syncthreads_or(dead);
         if (tid == NW * 64) flags[b] = 1 + (bad2 ? 4 : 0);
         if (bad2) {
             scan_general_body<Cfg::THREADS>(xin, wf32, zout, geom, rh, rw, 1, (float *)lds, b, tid);
             __syncthreads();
-            if (amax) { // the quads stored above are void: take the maximum of what the redo wrote
+            if (amax) { // the rows stored above are void: take the maximum of what the redo wrote
                 const float *zi = zout + (size_t)b * Cr * H * W;
                 zmax = 0.f;
                 for (int i = tid - NW * 64; i < Cr * H * W; i += NW * 64) zmax = fmaxf(zmax, fabsf(zi[i]));

@@ -57,19 +57,22 @@ template <int C, int KH, int KW> struct DuoCfg {
     static constexpr int NHL = 8;                        // landing slots of mailbox lines (lower part)
     static constexpr int OFF_HALO = OFF_DUMP + DUMPB;
     static constexpr int OFF_DMY = OFF_HALO + NHL * 1024; // landing of the mailbox prefetches no line is due for
-    static constexpr int OFF_BNC = OFF_DMY + NW * 1024;   // bounce buffers: one image row (C channels x 128 B) per helper
-    static constexpr int LDSB = OFF_BNC + NW * (C / 8) * 1024;
+    static constexpr int LDSB = OFF_DMY + NW * 1024;
     static constexpr int THREADS = 128 * NW;
     static constexpr int G = 4 / NW;       // rows per helper wave that start / finish a quad each step
     static constexpr int PF = 8;           // x quads are requested PF steps before their first use
     static constexpr int PFH = 3;          // mailbox lines are requested PFH steps before they are delivered
-    static constexpr int GATE = PFH + 3;   // the lower part starts once the upper part's diagonal 14 + GATE is visible
+#ifndef IFL_GATE
+#define IFL_GATE 2
+#endif
+    static constexpr int GATE = IFL_GATE;  // the lower part asks for its first line once the upper part's diagonal 14 + GATE is visible
     static_assert(PFH < NHL && PF >= PFH + 2, "the sweep's lead-in covers both prefetches");
     static_assert(4 % NW == 0 && C <= 64, "one DMA / store instruction covers one image row of all channels");
 };
 
 // Development aid (tools/exp_scan.sh): what-if builds that drop one kind of work (results are then garbage) to see what
-// a step is waiting for.  1: no x DMAs, 2: no z stores, 4: no z product, 8: no hand-off.  Never defined in the product.
+// a step is waiting for.  1: no x loads, 2: no z stores, 4: no z product, 8: no hand-off, 16: no mailbox prefetch.  Never
+// defined in the product.
 #ifndef IFL_EXP
 #define IFL_EXP 0
 #endif
@@ -77,7 +80,7 @@ template <int C, int KH, int KW> struct DuoCfg {
 #define IFL_PRIO_CHAIN 0
 #endif
 #ifndef IFL_PRIO_HELPER
-#define IFL_PRIO_HELPER 0
+#define IFL_PRIO_HELPER 1
 #endif
 #ifndef IFL_PRIO_ZPROD
 #define IFL_PRIO_ZPROD 3
@@ -175,6 +178,45 @@ template <int R0, int NIM> __device__ __forceinline__ void rb_read_all(unsigned 
                      "ds_read_b128 a[%9:%10], %2 offset:384\n\ts_mov_b64 exec, %0"
                      : "=&s"(sv)
                      : "s"(m), "v"(la), "n"(R0), "n"(R0 + 3), "n"(R0 + 4), "n"(R0 + 7), "n"(R0 + 8), "n"(R0 + 11), "n"(R0 + 12), "n"(R0 + 15)
+                     : "memory", IFL_AGPRS);
+}
+// a whole image row: global memory -> buffer, NIM full-wave loads at the lane offsets go[i] (asynchronous: vmcnt), and back
+// (s_nop 4: a scalar register written by a vector instruction -- a spill reload -- is read 5 states late by a vector-memory
+// instruction, and nobody inserts wait states in front of an asm statement)
+template <int R0, int NIM> __device__ __forceinline__ void rb_load_row(const unsigned (&go)[NIM], const char *src)
+{
+    if constexpr (NIM == 8)
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 a[%9:%10], %0, %8\n\tglobal_load_dwordx4 a[%11:%12], %1, %8\n\t"
+                     "global_load_dwordx4 a[%13:%14], %2, %8\n\tglobal_load_dwordx4 a[%15:%16], %3, %8\n\t"
+                     "global_load_dwordx4 a[%17:%18], %4, %8\n\tglobal_load_dwordx4 a[%19:%20], %5, %8\n\t"
+                     "global_load_dwordx4 a[%21:%22], %6, %8\n\tglobal_load_dwordx4 a[%23:%24], %7, %8" ::"v"(go[0]),
+                     "v"(go[1]), "v"(go[2]), "v"(go[3]), "v"(go[4]), "v"(go[5]), "v"(go[6]), "v"(go[7]), "s"(src), "n"(R0), "n"(R0 + 3),
+                     "n"(R0 + 4), "n"(R0 + 7), "n"(R0 + 8), "n"(R0 + 11), "n"(R0 + 12), "n"(R0 + 15), "n"(R0 + 16), "n"(R0 + 19), "n"(R0 + 20),
+                     "n"(R0 + 23), "n"(R0 + 24), "n"(R0 + 27), "n"(R0 + 28), "n"(R0 + 31)
+                     : "memory", IFL_AGPRS);
+    else
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 a[%5:%6], %0, %4\n\tglobal_load_dwordx4 a[%7:%8], %1, %4\n\t"
+                     "global_load_dwordx4 a[%9:%10], %2, %4\n\tglobal_load_dwordx4 a[%11:%12], %3, %4" ::"v"(go[0]),
+                     "v"(go[1]), "v"(go[2]), "v"(go[3]), "s"(src), "n"(R0), "n"(R0 + 3), "n"(R0 + 4), "n"(R0 + 7), "n"(R0 + 8), "n"(R0 + 11),
+                     "n"(R0 + 12), "n"(R0 + 15)
+                     : "memory", IFL_AGPRS);
+}
+template <int R0, int NIM> __device__ __forceinline__ void rb_store_row(const unsigned (&go)[NIM], char *dst)
+{
+    if constexpr (NIM == 8)
+        asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, a[%9:%10], %8\n\tglobal_store_dwordx4 %1, a[%11:%12], %8\n\t"
+                     "global_store_dwordx4 %2, a[%13:%14], %8\n\tglobal_store_dwordx4 %3, a[%15:%16], %8\n\t"
+                     "global_store_dwordx4 %4, a[%17:%18], %8\n\tglobal_store_dwordx4 %5, a[%19:%20], %8\n\t"
+                     "global_store_dwordx4 %6, a[%21:%22], %8\n\tglobal_store_dwordx4 %7, a[%23:%24], %8" ::"v"(go[0]),
+                     "v"(go[1]), "v"(go[2]), "v"(go[3]), "v"(go[4]), "v"(go[5]), "v"(go[6]), "v"(go[7]), "s"(dst), "n"(R0), "n"(R0 + 3),
+                     "n"(R0 + 4), "n"(R0 + 7), "n"(R0 + 8), "n"(R0 + 11), "n"(R0 + 12), "n"(R0 + 15), "n"(R0 + 16), "n"(R0 + 19), "n"(R0 + 20),
+                     "n"(R0 + 23), "n"(R0 + 24), "n"(R0 + 27), "n"(R0 + 28), "n"(R0 + 31)
+                     : "memory", IFL_AGPRS);
+    else
+        asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, a[%5:%6], %4\n\tglobal_store_dwordx4 %1, a[%7:%8], %4\n\t"
+                     "global_store_dwordx4 %2, a[%9:%10], %4\n\tglobal_store_dwordx4 %3, a[%11:%12], %4" ::"v"(go[0]),
+                     "v"(go[1]), "v"(go[2]), "v"(go[3]), "s"(dst), "n"(R0), "n"(R0 + 3), "n"(R0 + 4), "n"(R0 + 7), "n"(R0 + 8), "n"(R0 + 11),
+                     "n"(R0 + 12), "n"(R0 + 15)
                      : "memory", IFL_AGPRS);
 }
 // one register of a buffer under a lane mask: -> LDS, <- LDS (asynchronous), -> global memory
@@ -544,26 +586,22 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
         const unsigned fadr = ldsbase + RBB + g * 256 + n * 16; // this lane's B piece of the tile's row n (slot 0)
         const unsigned zadr = ldsbase + Cfg::OFF_ZQ + n * Cfg::ZROWB + c0 * 16;
         // ---- x and z of this wave's image rows live in REGISTERS, one full 128-byte line per (channel, row) ------------
-        // Tile row r belongs to helper r % NW, as buffer k = r / NW of NIM 16-byte registers per lane.  A row is fetched
-        // whole, by NI = C / CPI LDS-DMA instructions in which NQL = W/4 consecutive lanes cover one (channel, row) line:
-        // every request is a full line, fetched once (lane = channel x quad of the line; the round-1 kernel asked for 16
-        // bytes of a line every fourth step and the L2 had lost the line by then: 5.6 x the algorithmic fetch, and its
-        // partial-line stores were the most expensive thing in the kernel).  The DMA lands in a bounce buffer in LDS (one row
-        // per helper), and just before the row's first pixel is due the helper copies it into its registers.  From then on,
-        // every fourth step, the lanes that hold the row's next quad write it to the x staging, PFX steps before the chain
-        // waves need it; PFX + 7 steps later the same lanes and registers receive the finished z quad from the z staging,
-        // and when the last quad is in, the row goes out as whole lines.  No partial line ever moves.
-        // Nothing asynchronous ever targets these registers (the DMA has no register destination, the LDS reads that fill
-        // them wait inside their own asm statement): the compiler may move the buffers around as it likes.
-        constexpr int RPH = 16 / NW, NIM = C / 8, PFX = 2;
-        const int NQL = W >> 2;                 // quads per image row (<= 8: W <= 32)
-        const int CPI = 64 / NQL;               // channels per instruction
-        const int NI = (Cr + CPI - 1) / CPI;    // instructions per row (<= NIM)
-        const int lq = lane % NQL, lc = lane / NQL; // this lane's quad of the line and channel within the instruction
-        // number of instructions in which this lane carries a channel of the layer (0 for idle lanes)
-        const int imax = lc < CPI ? (Cr - lc + CPI - 1) / CPI : 0;
-        const unsigned goff0 = (unsigned)(lc * H * W * 4 + lq * 16); // byte offset inside an image: channel lc, quad lq
-        const unsigned gstep = (unsigned)(CPI * H * W * 4);          // ... per instruction
+        // Helper w owns the tile rows RPH w .. RPH w + RPH - 1, as buffers k = 0 .. RPH-1 of NIM 16-byte registers per lane
+        // (the accumulator registers a0 .. a127, by number: see rb_*).  A row is loaded whole, PFR steps before its first
+        // pixel is due, by NIM instructions in which 8 consecutive lanes cover one (channel, row) line of 32 pixels: every
+        // request is a full line, fetched once (lane = 8 channels x 8 quads; the round-1 kernel asked for 16 bytes of a line
+        // every fourth step and the L2 had lost the line by then: 5.6 x the algorithmic fetch, and its partial-line stores
+        // were the most expensive thing in the kernel).  Every fourth step the lanes that hold the row's next quad write it to
+        // the x staging, PFX steps before the chain waves need it; PFX + 7 steps later the same lanes and registers receive
+        // the finished z quad from the z staging, and when the last quad is in, the row goes out as whole lines.  No LDS-DMA,
+        // no partial line ever moves.  The step loop is unrolled by four: the row that is due depends on the step modulo 4
+        // only, so the registers are named at compile time.
+        static_assert(!PAD, "the duo scan takes layers of exactly 32 or 64 channels (launch_scan_mfma routes the others)");
+        constexpr int RPH = 16 / NW, NIM = C / 8, PFR = Cfg::PF, PFX = 2, NQL = 8; // (W = 32: 8 quads per row)
+        const int lq = lane & 7, lc = lane >> 3; // this lane's quad of the line and channel within the instruction
+        unsigned go[NIM];                        // byte offset inside an image of what this lane moves in instruction i
+#pragma unroll
+        for (int i = 0; i < NIM; ++i) go[i] = (unsigned)((8 * i + lc) * H * W * 4 + lq * 16);
         const char *xg = (const char *)xin + (size_t)b * Cr * H * W * sizeof(float);
         char *zg = (char *)zout + (size_t)b * Cr * H * W * sizeof(float);
         const unsigned dmy = __builtin_amdgcn_readfirstlane(ldsbase + Cfg::OFF_DMY + wv * 1024);
@@ -679,135 +717,21 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                     }
                 };
 
-                // masks of the lanes that carry data (all instructions but the row's last / the last one: a layer whose
-                // channel count is no multiple of CPI ends inside it), and the same restricted to one quad of the line
-                const unsigned long long m_all = __builtin_amdgcn_ballot_w64(lc < CPI);
-                const unsigned long long m_end = __builtin_amdgcn_ballot_w64(NI - 1 < imax);
-                const bool plain = NI == NIM && m_end == m_all; // every instruction of a row is alike (no padded channels)
-                const unsigned bnc = __builtin_amdgcn_readfirstlane(ldsbase + Cfg::OFF_BNC + wv * (NIM * 1024));
-
-                // row r -> bounce buffer (LDS-DMA, whole lines)
-                auto row_fetch = [&](const int r) {
-                    if (r >= Hp || (IFL_EXP & 1)) return;
-                    const char *src = xg + row_off(r);
+                // vector-memory operations this wave issues behind the loads of its buffer k, up to that row's first use:
+                // the loads of its later rows, and (mailbox helper) one mailbox operation in each of the PFR - PFX steps
+                int behind[RPH];
 #pragma unroll
-                    for (int i = 0; i < NIM; ++i)
-                        if (i < NI) { // (wave-uniform: every instruction issued has a lane: exact operation count)
-                            const unsigned long long m = i == NI - 1 ? m_end : m_all;
-                            const unsigned go = goff0 + i * gstep;
-                            const unsigned dst = bnc + i * 1024;
-                            unsigned long long sv;
-                            asm volatile("s_mov_b32 m0, %1\n\t"
-                                         "s_mov_b64 %0, exec\n\t"
-                                         "s_mov_b64 exec, %2\n\t"
-                                         "s_nop 4\n\t" // (a scalar register written by a vector instruction -- a spill reload -- is read 5 states late)
-                                         "global_load_lds_dwordx4 %3, %4\n\t"
-                                         "s_mov_b64 exec, %0"
-                                         : "=&s"(sv)
-                                         : "s"(dst), "s"(m), "v"(go), "s"(src)
-                                         : "memory", "m0");
-                        }
-                };
-                // bounce buffer -> buffer K (complete on return)
-                auto row_take = [&](auto k_c) {
-                    constexpr int K = decltype(k_c)::value;
-                    rb_take<4 * K * NIM, NIM>(bnc + lane * 16);
-                };
-                // quad ql of row r (buffer K) -> x staging [row][ql & 1][channel][4]
-                auto row_x = [&](auto k_c, const int r, const int ql) {
-                    constexpr int K = decltype(k_c)::value;
-                    const int pq = rw ? NQL - 1 - ql : ql;
-                    const unsigned la = ldsbase + Cfg::OFF_XS + r * Cfg::XROWB + (ql & 1) * (C * 16) + lc * 16;
-                    const unsigned long long mq = __builtin_amdgcn_ballot_w64(lq == pq && lc < CPI);
-                    if (plain && CPI == 8) {
-                        rb_write_all<4 * K * NIM, NIM>(mq, la);
-                    } else {
-                        auto one = [&](auto i_c) {
-                            constexpr int I = decltype(i_c)::value;
-                            if (I < NI) rb_write_one<4 * (K * NIM + I)>(mq & (I == NI - 1 ? m_end : m_all), la + I * CPI * 16);
-                        };
-                        one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
-                        one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
-                        if constexpr (NIM == 8) {
-                            one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
-                            one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
-                        }
-                    }
-                };
-                // finished z quad ql of row r (staged through the previous step) -> the registers its x came from
-                // (asynchronous: the end-of-step wait covers it)
-                auto row_z = [&](auto k_c, const int r, const int ql) {
-                    constexpr int K = decltype(k_c)::value;
-                    const int pq = rw ? NQL - 1 - ql : ql;
-                    const unsigned la = ldsbase + Cfg::OFF_ZQ + r * Cfg::ZROWB + (ql & 1) * (C * 16) + lc * 16;
-                    const unsigned long long mq = __builtin_amdgcn_ballot_w64(lq == pq && lc < CPI);
-                    if (plain && CPI == 8) {
-                        rb_read_all<4 * K * NIM, NIM>(mq, la);
-                    } else {
-                        auto one = [&](auto i_c) {
-                            constexpr int I = decltype(i_c)::value;
-                            if (I < NI) rb_read_one<4 * (K * NIM + I)>(mq & (I == NI - 1 ? m_end : m_all), la + I * CPI * 16);
-                        };
-                        one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
-                        one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
-                        if constexpr (NIM == 8) {
-                            one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
-                            one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
-                        }
-                    }
-                };
-                auto row_out = [&](auto k_c, const int r) {
-                    constexpr int K = decltype(k_c)::value;
-                    {
-                        char *dst = zg + row_off(r);
-                        auto one = [&](auto i_c) {
-                            constexpr int I = decltype(i_c)::value;
-                            if (I < NI) rb_store_one<4 * (K * NIM + I)>(I == NI - 1 ? m_end : m_all, goff0 + I * gstep, dst);
-                        };
-                        one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
-                        one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
-                        if constexpr (NIM == 8) {
-                            one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
-                            one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
-                        }
-                    }
-                };
-                // the rows r = c + 4 j of this wave, with their buffers (compile-time): op(K, r)
-                auto for_rows = [&](const int c, auto &&op) {
-                    if constexpr (NW == 4) {
-                        op(std::integral_constant<int, 0>{}, c);
-                        op(std::integral_constant<int, 1>{}, c + 4);
-                        op(std::integral_constant<int, 2>{}, c + 8);
-                        op(std::integral_constant<int, 3>{}, c + 12);
-                    } else if (c < 2) {
-                        op(std::integral_constant<int, 0>{}, c);
-                        op(std::integral_constant<int, 2>{}, c + 4);
-                        op(std::integral_constant<int, 4>{}, c + 8);
-                        op(std::integral_constant<int, 6>{}, c + 12);
-                    } else {
-                        op(std::integral_constant<int, 1>{}, c);
-                        op(std::integral_constant<int, 3>{}, c + 4);
-                        op(std::integral_constant<int, 5>{}, c + 8);
-                        op(std::integral_constant<int, 7>{}, c + 12);
-                    }
-                };
-
-                if (consume && mbox) {
-                    // gate: start once the upper part's diagonal 14 + GATE is visible, so that every prefetch finds its line
-                    uintx4 q;
-#ifdef IFL_STAMPS
-                    const unsigned long long g0 = __builtin_amdgcn_s_memrealtime();
-#endif
-                    poll_line(14 + Cfg::GATE < u_last ? 14 + Cfg::GATE : u_last, q);
-#ifdef IFL_STAMPS
-                    st_gate = __builtin_amdgcn_s_memrealtime() - g0;
-                    st_slow = 0;
-#endif
+                for (int k = 0; k < RPH; ++k) {
+                    int n = (mbox ? PFR - PFX : 0);
+#pragma unroll
+                    for (int k2 = k + 1; k2 < RPH; ++k2)
+                        if (k2 - k <= PFR - PFX && RPH * wv + k2 < Hp) n += NIM; // (loaded k2 - k steps later: before the use)
+                    behind[k] = n;
                 }
-                // this wave's first row is on its way before the first step
-                row_fetch(wv);
 
-                auto step = [&](const int d) {
+                // ---- one step; P = d mod 4 (compile-time: it names the row buffers that are due) ----
+                auto step = [&](auto p_c, const int d) {
+                    constexpr int P = decltype(p_c)::value;
                     IFL_HSTAMP(6); // (the wait at the end of the previous step)
                     asm volatile("s_barrier" ::: "memory");
                     IFL_HSTAMP(0); // barrier
@@ -835,32 +759,50 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                     if (h_out)
                         asm volatile("ds_read_b64 %0, %1" : "=v"(pv) : "v"(madr + RBB + ((d - 1) & 1) * SLOTB) : "memory");
                     IFL_HSTAMP(1); // requests
-                    // ---- x duty: the rows r = d + PFX (mod 4) start a quad PFX steps from now; they all belong to one helper
+                    // ---- load duty: the row whose first pixel is PFR steps away (this wave's rows come up in consecutive steps)
                     {
-                        const int c = (d + PFX) & 3;
-                        if ((c % NW) == wv) {
-                            const int q0 = (d + PFX - c) >> 2; // quad of row c; row c + 4 j is at quad q0 - j
-                            // the row whose first quad this is comes out of the bounce buffer, and the next one goes in
-                            for_rows(c, [&](auto k_c, const int r) {
-                                if (r < Hp && ((d + PFX - r) >> 2) == 0) {
-                                    // its DMA is complete: behind it this wave issued the mailbox operations of the steps since
-                                    // (one per step, mailbox helper only), nothing else
-                                    if (mbox) wait_vm(r < NW ? r + Cfg::PF - PFX : NW);
-                                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                                    row_take(k_c);
-                                    row_fetch(r + NW);
-                                }
-                            });
-                            for_rows(c, [&](auto k_c, const int r) {
-                                const int ql = (d + PFX - r) >> 2;
-                                if (r < Hp && ql >= 0 && ql < NQL) row_x(k_c, r, ql);
-                            });
-                            (void)q0;
+                        const int r = d + PFR; // (r mod 4 = P)
+                        if (r >= 0 && r < Hp && r / RPH == wv && !(IFL_EXP & 1)) {
+                            const char *src = xg + row_off(r);
+                            if constexpr (RPH == 4) {
+                                rb_load_row<4 * P * NIM, NIM>(go, src);
+                            } else {
+                                if ((r >> 2) & 1) rb_load_row<4 * (P + 4) * NIM, NIM>(go, src);
+                                else rb_load_row<4 * P * NIM, NIM>(go, src);
+                            }
+                        }
+                    }
+                    // ---- x duty: quad ql of this wave's row(s) r = d + PFX (mod 4) -> x staging [row][ql & 1][channel][4]
+#pragma unroll
+                    for (int j = 0; j < RPH / 4; ++j) {
+                        constexpr int KX0 = (P + PFX) & 3;
+                        const int r = RPH * wv + KX0 + 4 * j;
+                        const int ql = (d + PFX - r) >> 2;
+                        if (r < Hp && ql >= 0 && ql < NQL) { // (wave-uniform)
+                            if (ql == 0) wait_vm(behind[KX0 + 4 * j]); // the row has landed (first use)
+                            const int pq = rw ? NQL - 1 - ql : ql;
+                            const unsigned la = ldsbase + Cfg::OFF_XS + r * Cfg::XROWB + (ql & 1) * (C * 16) + lc * 16;
+                            if (j == 0) rb_write_all<4 * KX0 * NIM, NIM>(0x0101010101010101ull << pq, la);
+                            else rb_write_all<4 * ((KX0 + 4) % RPH) * NIM, NIM>(0x0101010101010101ull << pq, la);
                         }
                     }
                     // ---- the mailbox helper issues exactly one vector-memory operation per step besides its rows:
                     //      the line to be delivered PFH steps from now (lower part) ...
-                    if (consume && mbox) {
+                    if (consume && mbox && d == -2 - PFH) {
+                        // gate: the first line is requested once the upper part's diagonal 14 + GATE is visible, so that every
+                        // later request (one per step, like the upper part's lines) finds its line; the steps before this one
+                        // (this tile's first rows are on their way) did not have to wait for the upper part
+                        uintx4 q;
+#ifdef IFL_STAMPS
+                        const unsigned long long g0 = __builtin_amdgcn_s_memrealtime();
+#endif
+                        poll_line(14 + Cfg::GATE < u_last ? 14 + Cfg::GATE : u_last, q);
+#ifdef IFL_STAMPS
+                        st_gate = __builtin_amdgcn_s_memrealtime() - g0;
+                        st_slow = 0;
+#endif
+                    }
+                    if (consume && mbox && !(IFL_EXP & 16)) {
                         const int dl = d + PFH;
                         const bool ok = dl >= -2 && dl <= dl_last;
                         const char *line = mb + (size_t)(ok ? dl + 16 : 0) * DUO_LINEB;
@@ -870,7 +812,7 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                                      "global_load_lds_dwordx4 %1, %2 sc0 sc1" ::"s"(dst), "v"(lane * 16), "s"(line)
                                      : "memory", "m0");
                     }
-                    IFL_HSTAMP(2); // x quads
+                    IFL_HSTAMP(2); // row load + x quad
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     IFL_HSTAMP(3); // LDS wait
                     // ---- hand-off in: rows 14, 15 of the upper part's diagonal d + 16 join diagonal d of this tile's ring
@@ -890,11 +832,10 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                             asm volatile("s_setprio " IFL_STR(IFL_PRIO_ZPROD) : "+v"(Fh[0]), "+v"(Fl[0]), "+v"(Fh[1]), "+v"(Fl[1]));
                         else
                             asm volatile("s_setprio " IFL_STR(IFL_PRIO_ZPROD) : "+v"(Fh[0]), "+v"(Fl[0]));
-                        // (as asm with the accumulators in ordinary registers: with 2 waves per SIMD the row buffers fill the
-                        // accumulator half of the register file.  The first product of each accumulator takes the constant 0:
-                        // a register zeroed by a vector instruction just before would be read too early -- nobody inserts wait
-                        // states around an asm MFMA.  Same products in the same order as the chain wave's z product of
-                        // scan_mfma.hip: bit-identical results.)
+                        // (as asm with the accumulators in ordinary registers: the row buffers fill the accumulator half of the
+                        // register file.  The first product of each accumulator takes the constant 0: a register zeroed by a
+                        // vector instruction just before would be read too early -- nobody inserts wait states around an asm
+                        // MFMA.  Same products in the same order as the chain wave's z product of scan_mfma.hip: bit-identical.)
                         asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(zh) : "v"(Z[0][0]), "v"(Fh[0]));
                         asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(zm) : "v"(Z[0][0]), "v"(Fl[0]));
 #pragma unroll
@@ -918,23 +859,23 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                         char *line = mb + (size_t)(h_out ? u : DUO_LINES - 2) * DUO_LINEB;
                         asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(lane * 16), "v"(q), "s"(line) : "memory");
                     }
-                    // ---- z duty: the rows r = d - 5 (mod 4) completed a quad of z with diagonal d-2 (staged one step ago)
-                    {
-                        const int c = (d - 5) & 3;
-                        if ((c % NW) == wv) {
-                            bool last = false;
-                            for_rows(c, [&](auto k_c, const int r) {
-                                const int ql = (d - 5 - r) >> 2;
-                                if (r < Hp && ql >= 0 && ql < NQL) {
-                                    row_z(k_c, r, ql);
-                                    last = last || ql == NQL - 1;
-                                }
-                            });
-                            if (last && !(IFL_EXP & 2)) { // a row's last quad: the row goes out as whole lines
+                    // ---- z duty: this wave's row(s) r = d - 5 (mod 4) completed a quad of z with diagonal d-2 (staged one step
+                    //      ago); it joins the registers its x came from, and the row's last quad sends the row out
+#pragma unroll
+                    for (int j = 0; j < RPH / 4; ++j) {
+                        constexpr int KZ0 = (P + 3) & 3; // (d - 5) mod 4
+                        const int r = RPH * wv + KZ0 + 4 * j;
+                        const int ql = (d - 5 - r) >> 2;
+                        if (r < Hp && ql >= 0 && ql < NQL) { // (wave-uniform)
+                            const int pq = rw ? NQL - 1 - ql : ql;
+                            const unsigned la = ldsbase + Cfg::OFF_ZQ + r * Cfg::ZROWB + (ql & 1) * (C * 16) + lc * 16;
+                            if (j == 0) rb_read_all<4 * KZ0 * NIM, NIM>(0x0101010101010101ull << pq, la);
+                            else rb_read_all<4 * ((KZ0 + 4) % RPH) * NIM, NIM>(0x0101010101010101ull << pq, la);
+                            if (ql == NQL - 1 && !(IFL_EXP & 2)) {
                                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                                for_rows(c, [&](auto k_c, const int r) {
-                                    if (r < Hp && ((d - 5 - r) >> 2) == NQL - 1) row_out(k_c, r);
-                                });
+                                char *dst = zg + row_off(r);
+                                if (j == 0) rb_store_row<4 * KZ0 * NIM, NIM>(go, dst);
+                                else rb_store_row<4 * ((KZ0 + 4) % RPH) * NIM, NIM>(go, dst);
                             }
                         }
                     }
@@ -953,10 +894,19 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                         // ring keeps it) or is zero, so the maximum over everything staged is the maximum over the image
                         zmax = fmaxf(fmaxf(zmax, fabsf(zv[0])), fmaxf(fabsf(zv[1]), fmaxf(fabsf(zv[2]), fabsf(zv[3]))));
                     }
-                    IFL_HSTAMP(5); // z quads + staging
+                    IFL_HSTAMP(5); // z quad + staging
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // x quads and z staged by this wave are in LDS
                 };
-                for (int d = -Cfg::PF; d <= ND + 1; ++d) step(d);
+                static_assert(PFR % 4 == 0, "the sweep starts at a step that is 0 modulo 4");
+                for (int d = -PFR; d <= ND + 1; d += 4) {
+                    step(std::integral_constant<int, 0>{}, d);
+                    if (d + 1 > ND + 1) break;
+                    step(std::integral_constant<int, 1>{}, d + 1);
+                    if (d + 2 > ND + 1) break;
+                    step(std::integral_constant<int, 2>{}, d + 2);
+                    if (d + 3 > ND + 1) break;
+                    step(std::integral_constant<int, 3>{}, d + 3);
+                }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             // ================================ between the sweeps ========================================================
@@ -1035,8 +985,9 @@ int scan_duo_max_images() { return DUO_MAX_IMAGES; }
 
 bool scan_duo_supported(const Geom &g)
 {
-    // (the same shapes as the whole-image MFMA scan: launch_scan_mfma decides between the two)
-    return g.W <= 64;
+    // layers of exactly 32 or 64 channels on 32-pixel rows: the helper waves move whole 128-byte lines, 8 lanes per line
+    // (every other shape the MFMA scan covers runs on the whole-image kernel of scan_mfma.hip)
+    return (g.C == 32 || g.C == 64) && g.W == 32 && g.H <= 32 && ((g.KH == 3 && g.KW == 3) || (g.KH == 2 && g.KW == 2));
 }
 
 template <int C, int KH, int KW, bool PAD>
@@ -1068,11 +1019,9 @@ static int launch_duo(const float *x, float *z, const void *apack, const Geom &g
 int launch_scan_duo(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, int *flags,
                     const float *wf32, unsigned *amax, void *state, hipStream_t s)
 {
-    const int ct = mfma_padded_channels(g.C);
 #define IFL_CASE(CC, KK)                                                                                               \
-    if (ct == CC && g.KH == KK && g.KW == KK)                                                                          \
-        return g.C == CC ? launch_duo<CC, KK, KK, false>(x, z, apack, g, rh, rw, flags, wf32, amax, (char *)state, s)  \
-                         : launch_duo<CC, KK, KK, true>(x, z, apack, g, rh, rw, flags, wf32, amax, (char *)state, s);
+    if (g.C == CC && g.KH == KK && g.KW == KK)                                                                         \
+        return launch_duo<CC, KK, KK, false>(x, z, apack, g, rh, rw, flags, wf32, amax, (char *)state, s);
     IFL_CASE(64, 3)
     IFL_CASE(32, 3)
     IFL_CASE(64, 2)

@@ -1386,27 +1386,7 @@ static int launch_one(const float *x, float *z, const void *apack, const Geom &g
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &ptr, sizeof(ptr));
     }
 #endif
-    if constexpr (NTILE == 2) {
-        // Split the image over two workgroups when that still leaves one compute unit per workgroup (k_scan_split).
-        // IFL_NO_SPLIT=1 keeps the whole-image mapping.
-        const char *ns = getenv("IFL_NO_SPLIT"); // (read per launch: the tests flip it)
-        const bool no_split = ns && atoi(ns);
-        char *st = nullptr;
-        if (!no_split && g.B <= SPLIT_MAX_IMAGES && 2 * g.B <= device_cus() && (st = split_state(s))) {
-            static bool attr_s = false;
-            if (!attr_s) {
-                IFL_HIP(hipFuncSetAttribute((const void *)k_scan_split<C, KH, KW, PAD>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDSB));
-                attr_s = true;
-            }
-            static_assert(ScanCfg<C, KH, KW, 1>::LDSB_SPLIT <= Cfg::LDSB, "the redo of a split scan runs in the same allocation");
-            const SplitState sp{(unsigned long long *)(st + SPLIT_MBOX_OFF), (unsigned *)st};
-            hipLaunchKernelGGL((k_scan_split<C, KH, KW, PAD>), dim3(16 * ((g.B + 7) / 8)), dim3(Cfg::THREADS), Cfg::LDSB, s,
-                               x, z, (const half8 *)apack, g.H, g.W, rh, rw, flags, wf32, g, amax, sp);
-            IFL_HIP(hipGetLastError());
-            return IFL_OK;
-        }
-    }
+    // (two workgroups per image: the duo form, scan_duo.hip -- launch_scan_mfma routes the shapes it takes there)
     hipLaunchKernelGGL((k_scan_mfma<C, KH, KW, NTILE, PAD>), dim3(g.B), dim3(Cfg::THREADS), Cfg::LDSB, s, x, z,
                        (const half8 *)apack, g.H, g.W, rh, rw, flags, wf32, g, amax);
     IFL_HIP(hipGetLastError());

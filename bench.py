@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
 """Headline benchmark: inverse-conv forward + backward images/s (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
 
-One *step* = one pass of the hot path over one synthetic batch: `inverse` (x -> z = A^-1 x) plus
-the fused backward (g, z -> dx, dW) at B=128, C=64, 32x32, K=3, fp32; with N > 1 every
-rank runs its own B=128 batch (weak scaling) and the step ends with the RCCL all-reduce of dW.
-Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+One *step* = one pass of the hot path over one synthetic batch: `inverse` (x -> z = A^-1 x) plus the fused backward
+(g, z -> dx, dW) at C=64, 32x32, K=3, fp32.  With N > 1 ranks (one process per GPU, RCCL) the batch is
+sharded -- weak scaling: B=128 per rank (default); strong scaling: B=128 in total, 128/N per rank -- and the
+step ends with the all-reduce of dW.  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+Run plainly with --gpus N > 1 (no WORLD_SIZE in the environment) this script starts its own N ranks through
+torch.distributed.run, before anything touches a GPU, and relays rank 0's line (the reference: one process,
+nn.DataParallel, inf/if_multiGPU_imagenet32.py:410-411).  --dry --backend gloo runs the same control flow on CPU tensors
+without a kernel (the CPU test of the N > 1 path).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -20,18 +26,47 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 B, C, HH, WW, K = 128, 64, 32, 32, 3
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_* (f32 in/acc), dense
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense (the kernels issue f16 MFMAs)
 
 
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flags", type=int, default=0, help="IFL_FLAG_* bits passed to the library")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with hipEvents")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL)")
+    ap.add_argument("--dry", action="store_true", help="no kernels, CPU tensors: exercises launch, sharding and the collective")
+    ap.add_argument("--master-port", type=int, default=29533)
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """--gpus N > 1 without a torch.distributed.run environment: start the N ranks (nothing here has touched a GPU) and
+    relay rank 0's line."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
+           "127.0.0.1", "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if r.returncode != 0 or not lines:
+        sys.stderr.write(r.stdout[-4000:])
+        sys.exit(r.returncode or 1)
+    print(lines[-1], flush=True)
+    sys.exit(0)
+
+
 def ref_init_weight(gen):
     """inf/layers/inv_conv.py:153-170: dirac + xavier_normal(gain=0.01), W[c,-1,-1,-1] = 1."""
+    import torch
     w = torch.nn.init.dirac_(torch.empty(C, C, K, K))
     std = 0.01 * (2.0 / (2 * C * K * K)) ** 0.5
     w = w + torch.randn(C, C, K, K, generator=gen) * std
@@ -65,60 +100,132 @@ def host_cores():
     return max(1, n)
 
 
-def cpu_baseline(w, budget_s=15.0):
-    """The CPU oracle (C restatement of the reference's exact solver, fp32, OpenMP over the batch as
-    the reference's commented prange(batchsize), inverse_op_cython.pyx:35) timed on this host on a
-    bounded sample of the same workload: inverse + dy + dw.  A reported baseline, not the target."""
+def cpu_baseline(w, budget_s=10.0, budget_1t_s=6.0):
+    """The CPU oracle (C restatement of the reference's exact solver, fp32, OpenMP over the batch as the reference's
+    commented prange(batchsize), inverse_op_cython.pyx:35) timed on this host on a bounded sample of the same workload:
+    inverse + dy + dw -- on all host cores, and on one thread (the reference ships single-threaded,
+    inverse_op_cython.pyx:32).  A reported baseline, not the target."""
+    import numpy as np
     from oracle import oracle as O
     O.build()
     cores = host_cores()
     rng = np.random.default_rng(0)
     wn = w.numpy().astype(np.float32)
-    nb = max(cores, 8)
-    total_img, total_t = 0, 0.0
-    while total_t < budget_s:
-        x = rng.standard_normal((nb, C, HH, WW)).astype(np.float32)
-        g = rng.standard_normal((nb, C, HH, WW)).astype(np.float32)
-        t0 = time.perf_counter()
-        z = O.inverse(x, wn, nthreads=cores)
-        u = O.dy(g, wn, nthreads=cores)
-        O.dw(z, u, (K, K), nthreads=cores)
-        total_t += time.perf_counter() - t0
-        total_img += nb
-    return {"value": total_img / total_t, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d images of the same B=128,C=64,32x32,K=3 fp32 workload (inverse+dy+dw) in %.1f s, "
-                      "oracle/liboracle.so with %d OpenMP threads" % (total_img, total_t, cores)}
+
+    def run(nthreads, nb, budget):
+        total_img, total_t = 0, 0.0
+        while total_t < budget:
+            x = rng.standard_normal((nb, C, HH, WW)).astype(np.float32)
+            g = rng.standard_normal((nb, C, HH, WW)).astype(np.float32)
+            t0 = time.perf_counter()
+            z = O.inverse(x, wn, nthreads=nthreads)
+            u = O.dy(g, wn, nthreads=nthreads)
+            O.dw(z, u, (K, K), nthreads=nthreads)
+            total_t += time.perf_counter() - t0
+            total_img += nb
+        return total_img, total_t
+
+    n_all, t_all = run(cores, max(cores, 8), budget_s)
+    n_one, t_one = run(1, 1, budget_1t_s)
+    return {"value": n_all / t_all, "unit": "images/s", "cores": cores, "kind": "port",
+            "one_thread": {"value": n_one / t_one, "unit": "images/s", "cores": 1},
+            "sample": "the C oracle (oracle/liboracle.so, fp32) on the same B=128,C=64,32x32,K=3 workload (inverse+dy+dw): "
+                      "%d images in %.1f s with %d OpenMP threads, %d images in %.1f s with one thread"
+                      % (n_all, t_all, cores, n_one, t_one)}
+
+
+def accuracy(H, w, x, g, flags, nimg=3):
+    """Relative L2 errors of z, dx, dW on a sub-batch of the bench's own inputs against the fp64 oracle, and the absolute
+    error of log|det A| (exactly 0 for the unit diagonal).  Outside the timed region."""
+    import numpy as np
+    import torch
+    from oracle import oracle as O
+    O.build()
+    xs, gs = x[:nimg].contiguous(), g[:nimg].contiguous()
+    z = H.inverse(xs, w, "TL", flags)
+    dx, dw, _ = H.backward(gs, z, w, "TL", flags)
+    _, ld = H.forward(z, w, "TL", flags, want_logdet=True)
+    x64, g64, w64 = xs.double().cpu().numpy(), gs.double().cpu().numpy(), w.double().cpu().numpy()
+    nt = host_cores()
+    z_o = O.inverse(x64, w64, nthreads=nt)
+    u_o = O.dy(g64, w64, nthreads=nt)
+    dw_o = O.dw(z_o, u_o, (K, K), nthreads=nt)
+
+    def rel(a, b):
+        return float(np.linalg.norm(a.double().cpu().numpy().ravel() - b.ravel()) / np.linalg.norm(b.ravel()))
+
+    return {"rel_err_z": rel(z, z_o), "rel_err_dx": rel(dx, u_o), "rel_err_dw": rel(dw, dw_o),
+            "logdet_abs_err": float(ld.abs().max().item()), "images": nimg,
+            "reference": "oracle/ (fp64 restatement of inf/utils/solve_mc.py:88-114 and the adjoint / outer-product forms)"}
+
+
+def committed_counters(kernel_us, world):
+    """HBM-side bytes and matrix-pipe busy fraction of the scan from the rocprofv3 --pmc passes of this same command whose
+    summaries profiles/LATEST.json names (PMC counters cannot be read from inside this process).  None when there is no
+    pointer, or when the kernel it was taken on is not the one that just ran (other name, launch time off by > 15 %)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "LATEST.json")) as f:
+            latest = json.load(f)
+        if world != 1 or abs(latest["scan_avg_us"] - kernel_us) > 0.15 * kernel_us:
+            return None, None, None
+        traffic = (latest["fetch_size_kib"] * latest["fetch_correction"] + latest["write_size_kib"]) * 1024.0
+        return traffic, latest.get("mfma_busy_frac"), latest.get("source")
+    except (OSError, KeyError, ValueError, TypeError):
+        return None, None, None
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--flags", type=int, default=0, help="IFL_FLAG_* bits passed to the library")
-    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with hipEvents")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
 
-    import invflow_hip as H
+    import torch
+    import torch.distributed as dist
     import data_parallel as dp
 
-    rank, local_rank, world = dp.init()
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
-    dev = torch.device("cuda", local_rank)
-    H.lib()
-
+    rank, local_rank, world = dp.init(args.backend or ("gloo" if args.dry else None))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the process group has %d ranks" % (args.gpus, world))
+    nb = B if args.scaling == "weak" else dp.shard_bounds(B, rank, world)[1] - dp.shard_bounds(B, rank, world)[0]
+    nb_total = B * world if args.scaling == "weak" else B
     gen = torch.Generator().manual_seed(0)
     w_host = ref_init_weight(gen)
     torch.manual_seed(1 + rank)
-    x = torch.randn(B, C, HH, WW, device=dev)
-    g = torch.randn(B, C, HH, WW, device=dev)
+
+    if args.dry:
+        # control flow only: sharding, the collective, max-over-ranks timing, rank 0's line
+        dw = torch.full((C, C, K, K), float(rank + 1))
+        for _ in range(args.warmup):
+            dp.allreduce_mean_(dw)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            dp.allreduce_mean_(dw)
+        if world > 1:
+            dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"metric": "dry run (no kernels)", "value": nb_total * args.steps / float(t.item()), "unit": "images/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": args.scaling,
+                              "per_rank_batch": nb, "dw_mean": float(dw.mean().item())}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    import invflow_hip as H
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    dev = torch.device("cuda", local_rank)
+    H.lib()
+    x = torch.randn(nb, C, HH, WW, device=dev)
+    g = torch.randn(nb, C, HH, WW, device=dev)
     w = w_host.to(dev)
     z = torch.empty_like(x)
     dx = torch.empty_like(x)
     dw = torch.empty_like(w)
-
     carry = H.new_carry(w)  # forward -> backward side channel of a step (what the autograd ctx carries)
 
     def step():
@@ -133,21 +240,36 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # per-kernel hipEvents (roofline leg) bracket the launches of every 5th step of the timed region only:
-    # an event pair around each of the 5 launches of a step costs ~30 us of a ~330 us step
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        H.profile_enable((not args.no_kernel_events) and i % 5 == 0)
+    for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    H.profile_enable(False)
-    prof = H.profile_collect()
 
-    # "also report forward + log-det (z -> x^) separately" -- outside the timed region of the metric
+    # ---- outside the timed region ---------------------------------------------------------------------------------------
+    # per-step device times (events recorded on the launch stream between the steps: no host synchronisation inside)
+    nper = max(100, min(args.steps, 400))
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(nper + 1)]
+    evs[0].record()
+    for i in range(nper):
+        step()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(nper))
+    # per-kernel device times (roofline leg): hipEvents recorded by the library around each tagged launch, on the launch
+    # stream; an event pair per launch costs ~6 us, so these steps are not part of `value`
+    prof = {}
+    if not args.no_kernel_events:
+        H.profile_enable(True)
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        H.profile_enable(False)
+        prof = H.profile_collect()
+    # "also report forward + log-det (z -> x^) separately"
     xh = torch.empty_like(z)
     for _ in range(3):
         H.forward(z, w, "TL", args.flags, out=xh, want_logdet=True)
@@ -165,62 +287,45 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = B * world * args.steps / elapsed
-        # dominant kernel = the tag with the largest device time
-        dom = max(prof, key=lambda k_: prof[k_][0])
-        ms, n = prof[dom]
-        if n == 0:
-            ms, n = float("nan"), 1
-        avg_s = ms / max(n, 1) * 1e-3
-        flops, nbytes = algorithmic(dom, B)
-        achieved = flops / avg_s / 1e12
-        # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process,
-        # so the figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/), corrected
-        # as MI355X_MICROARCH.md prescribes.  None when the committed counters are for another kernel / missing.
-        traffic, traffic_src = None, None
-        try:
-            cj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_final_scan_hbm_counters.json")
-            with open(cj) as f:
-                pc = json.load(f)
-            if dom == "scan" and world == 1:
-                traffic = (pc["fetch_size_kib"] * pc["fetch_correction"] + pc["write_size_kib"]) * 1024.0
-                traffic_src = "profiles/r01_final_scan_hbm_counters.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
-        except (OSError, KeyError, ValueError):
-            pass
-        # matrix-pipe busy fraction of the dominant kernel, same provenance (the SQ pass of tools/profile_round.sh)
-        mfma_busy = None
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_final_sq_counters.json")) as f:
-                sq = json.load(f)
-            if dom == "scan" and world == 1:
-                mfma_busy = sq["mfma_busy_frac"]
-        except (OSError, KeyError, ValueError):
-            pass
-        roofline = {
-            # the path is a dense CxC contraction (166 flop/B): MFMA-bound.  achieved = ALGORITHMIC flops
-            #  / measured launch time; the kernels issue 3 f16 MFMAs per algorithmic product
-            # (split fp16, fp32 accumulate), so the peak is the dense f16 MFMA peak.
-            "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-            "algorithmic_bytes": nbytes, "mfma_busy_frac": mfma_busy,
-            "issued_tflops": 3.0 * achieved, "frac_issued": 3.0 * achieved / MFMA_F16_PEAK_TFLOPS,
-            "frac_vs_f32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS,
-            "avg_launch_us": avg_s * 1e6, "launches": n,
-            "hbm_achieved_GBps": nbytes / avg_s / 1e9, "hbm_frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBPS,
-            "step_hbm_frac": (5.0 * B * C * HH * WW * 4) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "step_mfma_frac": (2 * algorithmic("scan", B)[0] + algorithmic("wgrad", B)[0]) / (ms_per_step * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-            "per_kernel_us": {k_: (v[0] / max(v[1], 1) * 1e3) for k_, v in prof.items() if v[1]},
-        }
+        value = nb_total * args.steps / elapsed
+        roofline = None
+        if prof and any(v[1] for v in prof.values()):
+            dom = max(prof, key=lambda k_: prof[k_][0])  # the tag with the largest device time
+            ms, n = prof[dom]
+            avg_s = ms / max(n, 1) * 1e-3
+            flops, nbytes = algorithmic(dom, nb)
+            achieved = flops / avg_s / 1e12
+            traffic, mfma_busy, src = committed_counters(avg_s * 1e6, world) if dom == "scan" else (None, None, None)
+            roofline = {
+                # the path is a dense CxC contraction (166 flop/B): MFMA-bound.  achieved = ALGORITHMIC flops /
+                # measured launch time; the kernels issue 3 f16 MFMAs per algorithmic product (split fp16, fp32 accumulate),
+                # so the peak is the dense f16 MFMA peak.
+                "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": src,
+                "algorithmic_bytes": nbytes, "mfma_busy_frac": mfma_busy,
+                "issued_tflops": 3.0 * achieved, "frac_issued": 3.0 * achieved / MFMA_F16_PEAK_TFLOPS,
+                "frac_vs_f32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS,
+                "avg_launch_us": avg_s * 1e6, "launches": n,
+                "hbm_achieved_GBps": nbytes / avg_s / 1e9, "hbm_frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBPS,
+                "step_hbm_frac": (5.0 * nb * C * HH * WW * 4) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "step_mfma_frac": (2 * algorithmic("scan", nb)[0] + algorithmic("wgrad", nb)[0]) / (ms_per_step * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                "per_kernel_us": {k_: (v[0] / max(v[1], 1) * 1e3) for k_, v in prof.items() if v[1]},
+            }
+        acc = accuracy(H, w, x, g, args.flags)
         out = {
             "metric": "inverse-conv fwd+bwd images/sec @ B=128,C=64,32x32; log-det rel-err",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f16x3-split (f32 in/out, f32 accumulate)", "data": "synthetic",
-            "config": {"workload": "configs[1]: single inverse-conv layer 3x3, C=64, 32x32, batch 128 per GPU, fp32: "
-                                   "inverse (x->z) + fused backward (g,z->dx,dW)" + ("; dW all-reduce over RCCL" if world > 1 else ""),
-                       "B": B, "C": C, "H": HH, "W": WW, "K": K, "logdet_abs_err": 0.0},
+            "config": {"workload": "configs[1]: single inverse-conv layer 3x3, C=64, 32x32, batch %d per GPU (%s scaling: %d in "
+                                   "total), fp32: inverse (x->z) + fused backward (g,z->dx,dW)" % (nb, args.scaling, nb_total)
+                                   + ("; dW all-reduce over RCCL" if world > 1 else ""),
+                       "B": nb, "C": C, "H": HH, "W": WW, "K": K, "logdet_abs_err": acc["logdet_abs_err"]},
+            "accuracy": acc,
+            "step_ms_percentiles": {"p10": per[int(0.1 * (nper - 1))], "p50": per[(nper - 1) // 2], "p90": per[int(0.9 * (nper - 1))],
+                                    "steps": nper, "what": "device time of single steps (stream events), outside the timed region"},
             "roofline": roofline,
-            "forward_logdet": {"ms": fwd_ms, "images_per_s": B / (fwd_ms * 1e-3),
+            "forward_logdet": {"ms": fwd_ms, "images_per_s": nb / (fwd_ms * 1e-3),
                                "what": "ifl_forward_f32: z -> x^ = A z and log|det A| (the layer's reverse), per rank, not part of value"},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -20,8 +20,9 @@
  *     IFL_FLAG_GENERAL_DIAG -- lower-triangular with w's own diagonal
  *     (inf/layers/emerging/inverse_op_cython.pyx:64).
  *   - The library never allocates device memory, never synchronises the device and keeps no
- *     global mutable state: scratch comes from the caller (`ws`, `ws_bytes`, size from
- *     ifl_workspace_bytes), work is enqueued on the caller's stream.  Re-entrant and
+ *     global mutable state: scratch (`ws`, `ws_bytes`, size from ifl_workspace_bytes) and the
+ *     persistent block of the two-workgroup scan (`scan_state`, below) are arguments, work is
+ *     enqueued on the caller's stream, no environment variable is read.  Re-entrant and
  *     thread-safe (the reference: legacy default stream + cudaDeviceSynchronize after every
  *     launch, inv_conv_with_bp_kernel_general.cu:113-124).
  *   - Return value: 0 on success, a negative IFL_E* code otherwise; ifl_last_error() gives
@@ -43,7 +44,8 @@ enum { IFL_ORDER_TL = 0, IFL_ORDER_TR = 1, IFL_ORDER_BL = 2, IFL_ORDER_BR = 3 };
 enum {
     IFL_FLAG_GENERAL_DIAG = 1u, /* divide by w[c,c,diag tap] instead of assuming 1 */
     IFL_FLAG_EXACT_F32 = 2u,    /* force the plain-fp32 arithmetic path (no split-precision MFMA) */
-    IFL_FLAG_NO_MFMA = 4u       /* force the general (any C, any K) VALU kernels */
+    IFL_FLAG_NO_MFMA = 4u,      /* force the general (any C, any K) VALU kernels */
+    IFL_FLAG_WHOLE_IMAGE = 8u   /* one workgroup per image even when a scan_state block is given (same bits either way) */
 };
 
 enum { IFL_OK = 0, IFL_EINVAL = -1, IFL_EUNSUPPORTED = -2, IFL_EWORKSPACE = -3, IFL_EHIP = -4 };
@@ -71,13 +73,25 @@ int ifl_profile_collect(int tag, double *total_ms, int *launches);
 size_t ifl_workspace_bytes(int op, int B, int C, int H, int W, int KH, int KW, unsigned flags);
 
 /*
+ * Persistent block of the two-workgroup scan.  Layers of 32 or 64 channels on 32-pixel rows with 17..32 rows run two
+ * workgroups per image (at most half as many images as compute units) that hand two rows per anti-diagonal over through
+ * a mailbox in this block.  The caller owns it: ifl_scan_state_bytes() bytes, 256-byte aligned, ZERO-FILLED once, then
+ * passed unchanged to every scan call of ONE stream (launches that use a block must not overlap in time; its contents --
+ * the mailbox and per-image launch generations -- advance on the device, so it is valid under graph replay).
+ * scan_state = NULL: one workgroup per image; results are bit-identical either way.
+ */
+size_t ifl_scan_state_bytes(void);
+
+/*
  * z = A^-1 x -- the layer's forward pass x -> z.
  * Replaces  inv_conv_with_bp.inverse(input, kernel, output)
  *   (inv_conv_with_bp_general.cpp:19-28 -> inv_conv_cuda_inverse, inv_conv_with_bp_kernel_general.cu:72-129),
  * called from inv_conv_.forward (inf/layers/inv_conv.py:46-60).  Exact semantics = solve_mc.py:88-114.
+ * z must not alias x (the scan re-reads x when an image has to be redone in a wider arithmetic).
  */
 int ifl_inverse_f32(const float *x, const float *w, float *z, int B, int C, int H, int W, int KH, int KW,
-                    int order, unsigned flags, void *ws, size_t ws_bytes, void *carry, ifl_stream_t stream);
+                    int order, unsigned flags, void *ws, size_t ws_bytes, void *carry, void *scan_state,
+                    ifl_stream_t stream);
 
 /*
  * Optional forward -> backward side channel (the analogue of ctx.save_for_backward, inf/layers/inv_conv.py:56):
@@ -110,11 +124,12 @@ int ifl_forward_f32(const float *z, const float *w, float *xhat, float *logdet, 
  *   recon_weight * mean_b ||x - A z||^2   w.r.t. w (z detached; cf. add_recon_grad,
  *   inf/layers/selfnorm.py:187-229) is accumulated in the same dW reduction and
  *   `recon_loss` (1 float, may be NULL) receives mean_b ||x - A z||^2.
- * `dx` may be NULL (weights-only) or `dw` may be NULL (input-gradient only).
+ * `dx` may be NULL (weights-only) or `dw` may be NULL (input-gradient only); dx must not alias g.
  */
 int ifl_backward_f32(const float *g, const float *z, const float *x, const float *w, float *dx, float *dw,
                      float recon_weight, float *recon_loss, int B, int C, int H, int W, int KH, int KW,
-                     int order, unsigned flags, void *ws, size_t ws_bytes, void *carry, ifl_stream_t stream);
+                     int order, unsigned flags, void *ws, size_t ws_bytes, void *carry, void *scan_state,
+                     ifl_stream_t stream);
 
 /*
  * The inverse-flow block: four layers of orders TL -> TR -> BL -> BR (Inv_FlowUnit, inf/layers/inv_flow.py:13-53).
@@ -127,21 +142,10 @@ int ifl_backward_f32(const float *g, const float *z, const float *x, const float
 size_t ifl_unit_workspace_bytes(int op, int B, int C, int H, int W, int KH, int KW, unsigned flags);
 int ifl_unit_inverse_f32(const float *x, const float *const w[4], float *const z[4], int B, int C, int H, int W,
                          int KH, int KW, unsigned flags, void *ws, size_t ws_bytes, void *const carry[4],
-                         ifl_stream_t stream);
+                         void *scan_state, ifl_stream_t stream);
 int ifl_unit_backward_f32(const float *gout, const float *const z[4], const float *const w[4], float *dx,
                           float *const dw[4], int B, int C, int H, int W, int KH, int KW, unsigned flags, void *ws,
-                          size_t ws_bytes, void *const carry[4], ifl_stream_t stream);
-
-/*
- * Optional persistent state of the split scan (two workgroups per image with an in-launch hand-off: used when
- * 16 < H <= 32 and 2 B <= the number of compute units).  The library never allocates: the caller provides ONE block of
- * ifl_scan_state_bytes() per (device, stream), 256-byte aligned, ZERO-FILLED once before it is registered, and keeps it
- * alive and untouched while registered (it holds the hand-off mailbox and per-image launch generations, which advance
- * on the device: valid under graph replay).  Without a registered block every scan uses the one-workgroup-per-image
- * kernel; results are bit-identical either way.  state = NULL unregisters the stream's block.
- */
-size_t ifl_scan_state_bytes(void);
-int ifl_scan_state_register(void *state, size_t bytes, ifl_stream_t stream);
+                          size_t ws_bytes, void *const carry[4], void *scan_state, ifl_stream_t stream);
 
 /*
  * Weight gradient from a precomputed dx:  dw = -(sum dx (x) shifted z) * mask.

@@ -1,6 +1,7 @@
 // C-ABI entry points of libinvflow_hip.so (see include/invflow.h for the contract and the
 // reference interfaces each one replaces).  Argument validation, workspace carving and
-// kernel selection only -- no device allocation, no synchronisation, no global state.
+// kernel selection only -- no device allocation, no synchronisation, no environment variable, and no state besides the
+// thread-local error text / profiling records and the once-per-device LDS opt-in latches (ifl_common.h).
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -144,7 +145,7 @@ static bool carry_usable(const Geom &g, unsigned flags)
 //   carry_in (backward, transposed): take the packed adjoint from the carry, collect max|dx| there.
 // *amax_valid tells the caller whether the scan wrote max|output| into the carry word.
 static int run_scan(const float *x, const float *w, float *z, const Geom &g, int transposed, unsigned flags,
-                    Carver &cv, void *carry_out, void *carry_in, bool *amax_valid, hipStream_t s)
+                    Carver &cv, void *carry_out, void *carry_in, bool *amax_valid, void *scan_state, hipStream_t s)
 {
     const size_t cp = cpad(g.C);
     double *linv = cv.take<double>(cp * cp);
@@ -180,7 +181,7 @@ static int run_scan(const float *x, const float *w, float *z, const Geom &g, int
         if (amax_valid) *amax_valid = amax != nullptr;
         // (an image whose r leaves the fp16 range is redone in exact fp32 inside the same launch)
         ProfScope ps(IFL_PROF_SCAN, s);
-        return launch_scan_mfma(x, pack, z, g, rh, rw, ovf, pack32, amax, s);
+        return launch_scan_mfma(x, pack, z, g, rh, rw, ovf, pack32, amax, scan_state, (flags & IFL_FLAG_WHOLE_IMAGE) != 0, s);
     }
     {
         ProfScope ps(IFL_PROF_FOLD, s);
@@ -263,13 +264,7 @@ size_t ifl_workspace_bytes(int op, int B, int C, int H, int W, int KH, int KW, u
     }
 }
 
-size_t ifl_scan_state_bytes(void) { return scan_state_bytes(); }
-
-int ifl_scan_state_register(void *state, size_t bytes, ifl_stream_t stream)
-{
-    clear_error();
-    return scan_state_register(state, bytes, (hipStream_t)stream);
-}
+size_t ifl_scan_state_bytes(void) { return scan_duo_state_bytes(); }
 
 size_t ifl_carry_bytes(int C, int KH, int KW)
 {
@@ -278,17 +273,18 @@ size_t ifl_carry_bytes(int C, int KH, int KW)
 }
 
 int ifl_inverse_f32(const float *x, const float *w, float *z, int B, int C, int H, int W, int KH, int KW, int order,
-                    unsigned flags, void *ws, size_t ws_bytes, void *carry, ifl_stream_t stream)
+                    unsigned flags, void *ws, size_t ws_bytes, void *carry, void *scan_state, ifl_stream_t stream)
 {
     clear_error();
     int rc = check_shape("ifl_inverse_f32", B, C, H, W, KH, KW, order);
     if (rc) return rc;
     if (B == 0) return IFL_OK;
     if (!x || !w || !z) IFL_FAIL(IFL_EINVAL, "ifl_inverse_f32: null tensor pointer");
+    if (x == z) IFL_FAIL(IFL_EINVAL, "ifl_inverse_f32: z must not alias x (an image that leaves the fp16 range is redone from x)");
     Geom g = make_geom(B, C, H, W, KH, KW, order, flags);
     Carver cv(ws, ws_bytes);
     bool amax_ok = false;
-    rc = run_scan(x, w, z, g, 0, flags, cv, carry, nullptr, &amax_ok, (hipStream_t)stream);
+    rc = run_scan(x, w, z, g, 0, flags, cv, carry, nullptr, &amax_ok, scan_state, (hipStream_t)stream);
     if (rc) return rc;
     if (carry && carry_usable(g, flags) && !amax_ok) {
         // the general scan ran (unaligned pointers): collect max|z| with a streaming pass (rare path)
@@ -367,13 +363,14 @@ int ifl_dw_f32(const float *z, const float *dx, float *dw, int B, int C, int H, 
 
 int ifl_backward_f32(const float *gout, const float *z, const float *x, const float *w, float *dx, float *dw,
                      float recon_weight, float *recon_loss, int B, int C, int H, int W, int KH, int KW, int order,
-                     unsigned flags, void *ws, size_t ws_bytes, void *carry, ifl_stream_t stream)
+                     unsigned flags, void *ws, size_t ws_bytes, void *carry, void *scan_state, ifl_stream_t stream)
 {
     clear_error();
     int rc = check_shape("ifl_backward_f32", B, C, H, W, KH, KW, order);
     if (rc) return rc;
     if (B > 0 && (!gout || !w)) IFL_FAIL(IFL_EINVAL, "ifl_backward_f32: null tensor pointer");
     if (B > 0 && dw && !z) IFL_FAIL(IFL_EINVAL, "ifl_backward_f32: dw requested but z is null");
+    if (B > 0 && dx && dx == gout) IFL_FAIL(IFL_EINVAL, "ifl_backward_f32: dx must not alias g (an image that leaves the fp16 range is redone from g)");
     if (!dx && !dw) return IFL_OK;
     hipStream_t s = (hipStream_t)stream;
     Geom g = make_geom(B, C, H, W, KH, KW, order, flags);
@@ -387,7 +384,7 @@ int ifl_backward_f32(const float *gout, const float *z, const float *x, const fl
     Carver cv(ws, ws_bytes);
     float *u = dx ? dx : cv.take<float>(n);
     bool dxmax_ok = false;
-    if ((rc = run_scan(gout, w, u, g, 1, flags, cv, nullptr, carry, &dxmax_ok, s))) return rc;
+    if ((rc = run_scan(gout, w, u, g, 1, flags, cv, nullptr, carry, &dxmax_ok, scan_state, s))) return rc;
     if (!dw) return IFL_OK;
     const float *gsrc = u;
     if (recon) {
@@ -441,7 +438,8 @@ size_t ifl_unit_workspace_bytes(int op, int B, int C, int H, int W, int KH, int 
 }
 
 int ifl_unit_inverse_f32(const float *x, const float *const w[4], float *const z[4], int B, int C, int H, int W, int KH,
-                         int KW, unsigned flags, void *ws, size_t ws_bytes, void *const carry[4], ifl_stream_t stream)
+                         int KW, unsigned flags, void *ws, size_t ws_bytes, void *const carry[4], void *scan_state,
+                         ifl_stream_t stream)
 {
     clear_error();
     int rc = check_shape("ifl_unit_inverse_f32", B, C, H, W, KH, KW, IFL_ORDER_TL);
@@ -464,7 +462,7 @@ int ifl_unit_inverse_f32(const float *x, const float *const w[4], float *const z
         if (ws_bytes < 4 * per) IFL_FAIL(IFL_EWORKSPACE, "ifl_unit_inverse_f32: workspace too small: need %zu bytes, have %zu", 4 * per, ws_bytes);
         for (int l = 0; l < 4; ++l)
             if ((rc = ifl_inverse_f32(in[l], w[l], z[l], B, C, H, W, KH, KW, kUnitOrder[l], flags, (char *)ws + l * per,
-                                      per, carry ? carry[l] : nullptr, stream)))
+                                      per, carry ? carry[l] : nullptr, scan_state, stream)))
                 return rc;
         return IFL_OK;
     }
@@ -491,14 +489,17 @@ int ifl_unit_inverse_f32(const float *x, const float *const w[4], float *const z
     }
     for (int l = 0; l < 4; ++l) {
         ProfScope ps(IFL_PROF_SCAN, s);
-        if ((rc = launch_scan_mfma(in[l], wf[l], z[l], g[l], g[l].flipH, g[l].flipW, ovf[l], wf2[l], co[l].zmax, s))) return rc;
+        if (in[l] == z[l]) IFL_FAIL(IFL_EINVAL, "ifl_unit_inverse_f32: a layer's output must not alias its input");
+        if ((rc = launch_scan_mfma(in[l], wf[l], z[l], g[l], g[l].flipH, g[l].flipW, ovf[l], wf2[l], co[l].zmax, scan_state,
+                                   (flags & IFL_FLAG_WHOLE_IMAGE) != 0, s)))
+            return rc;
     }
     return IFL_OK;
 }
 
 int ifl_unit_backward_f32(const float *gout, const float *const z[4], const float *const w[4], float *dx, float *const dw[4],
                           int B, int C, int H, int W, int KH, int KW, unsigned flags, void *ws, size_t ws_bytes,
-                          void *const carry[4], ifl_stream_t stream)
+                          void *const carry[4], void *scan_state, ifl_stream_t stream)
 {
     clear_error();
     int rc = check_shape("ifl_unit_backward_f32", B, C, H, W, KH, KW, IFL_ORDER_TL);
@@ -515,7 +516,7 @@ int ifl_unit_backward_f32(const float *gout, const float *const z[4], const floa
     for (int l = 3; l >= 0; --l) {
         float *gnext = l == 0 ? dx : ((l & 1) ? t0 : t1);
         if ((rc = ifl_backward_f32(gcur, z[l], nullptr, w[l], gnext, dw[l], 0.0f, nullptr, B, C, H, W, KH, KW, kUnitOrder[l],
-                                   flags, rest, rest_bytes, carry ? carry[l] : nullptr, stream)))
+                                   flags, rest, rest_bytes, carry ? carry[l] : nullptr, scan_state, stream)))
             return rc;
         gcur = gnext;
     }

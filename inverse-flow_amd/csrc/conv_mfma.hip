@@ -370,12 +370,8 @@ static int launch_conv_one(const float *in, const void *apack, const float *w, c
                            int pt, int pl, hipStream_t s)
 {
     using Cfg = ConvCfg<C, KH, KW, WT>;
-    static bool attr_done = false; // idempotent attribute, benign race
-    if (!attr_done) {
-        IFL_HIP(hipFuncSetAttribute((const void *)k_conv_mfma<C, KH, KW, WT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    Cfg::LDSB2));
-        attr_done = true;
-    }
+    static LdsOptIn opt_in;
+    if (int rc = lds_opt_in(opt_in, (const void *)k_conv_mfma<C, KH, KW, WT>, Cfg::LDSB2)) return rc;
 #ifdef IFL_STAMPS
     if (const char *e = getenv("IFL_CSTAMPS")) {
         unsigned long long *ptr = (unsigned long long *)strtoull(e, nullptr, 0);

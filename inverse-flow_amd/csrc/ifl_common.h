@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/invflow.h"
 
 namespace ifl {
@@ -26,6 +28,28 @@ void clear_error();
     } while (0)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Opt-in of a kernel to more than 64 KiB of dynamic LDS: an attribute of the function on a device, set once per
+// (kernel, device) behind std::call_once -- the only state the library keeps besides the thread-local error text, and it
+// never changes after its first use.
+static constexpr int IFL_MAX_DEVICES = 64;
+struct LdsOptIn {
+    std::once_flag once[IFL_MAX_DEVICES];
+    hipError_t err[IFL_MAX_DEVICES];
+};
+static inline int lds_opt_in(LdsOptIn &st, const void *fn, int bytes)
+{
+    int dev = 0;
+    IFL_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= IFL_MAX_DEVICES) {
+        IFL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        return IFL_OK;
+    }
+    std::call_once(st.once[dev], [&] { st.err[dev] = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); });
+    if (st.err[dev] != hipSuccess)
+        IFL_FAIL(IFL_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize, %d) failed: %s", bytes, hipGetErrorString(st.err[dev]));
+    return IFL_OK;
+}
 
 // Geometry of one inverse-conv problem in *logical* (TL-canonical) coordinates.
 // A layer of order TR/BL/BR is the TL operator seen through a reflection of the pixel grid and
@@ -88,25 +112,22 @@ struct FoldJobs {
     FoldJob job[4];
 };
 int launch_foldpack_jobs(const FoldJobs &jobs, int njobs, int ndir, hipStream_t s);
-// Split scan (H > 16 and at most half as many images as compute units): an image's two row tiles run on two
-// workgroups, the upper one handing the lower its last two rows of every diagonal through a mailbox.  The state
-// is a caller-owned zero-initialised block per device and stream (ifl_scan_state_register).
+// The duo form of the scan (scan_duo.hip): one workgroup per 16-row tile, chain waves + helper waves.  An image of 17..32
+// rows is two workgroups, the upper one handing the lower its last two rows of every diagonal through a mailbox in
+// `state`: the caller's block of ifl_scan_state_bytes (include/invflow.h), or NULL.
 struct SplitState {
-    unsigned long long *mbox; // [image][80 steps][wave][hi, lo][8 lanes] 16-byte {value, tag, value, tag} granule pairs
-    unsigned *gen;            // [image] launch generation: this launch's tag is gen + 1, the lower half advances it
+    unsigned long long *mbox; // [image][80 lines][1 KiB]: 8-byte {value, tag} granules
+    unsigned *gen;            // [image] launch generation: this launch's tags are gen + 1, gen + 2; the lower part advances it
 };
-size_t scan_state_bytes();
-int scan_state_register(void *state, size_t bytes, hipStream_t s); // (state = NULL: forget this stream's block)
-// The duo form of the scan (scan_duo.hip): one workgroup per 16-row tile, chain waves + helper waves; `state` = the
-// registered block (needed for images of more than 16 rows) or NULL.
 size_t scan_duo_state_bytes();
 int scan_duo_max_images();
 bool scan_duo_supported(const Geom &g);
 int launch_scan_duo(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, int *flags,
                     const float *wf32, unsigned *amax, void *state, hipStream_t s);
 // amax: optional device word that receives max|z| (atomicMax of float bits; must be cleared beforehand)
+// state: the caller's scan-state block or NULL; whole_image: keep one workgroup per image (IFL_FLAG_WHOLE_IMAGE)
 int launch_scan_mfma(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, int *flags,
-                     const float *wf32, unsigned *amax, hipStream_t s);
+                     const float *wf32, unsigned *amax, void *state, bool whole_image, hipStream_t s);
 
 // ---- MFMA weight gradient (wgrad_mfma.hip): C in {32,64}, W in {16,32}, K in {2x2,3x3}, corner pads ----
 bool wgrad_mfma_supported(int B, int C, int H, int W, int KH, int KW, int pt, int pl, const void *gz, const void *x);

@@ -127,11 +127,8 @@ int launch_linv(const float *w, double *linv, const Geom &g, hipStream_t s)
         hipLaunchKernelGGL(k_linv_blocked, dim3(1), dim3(1024), 0, s, w, linv, g);
     } else if (g.C <= 96) {
         const size_t lds = (size_t)g.C * g.C * (sizeof(double) + sizeof(float));
-        static bool attr_done = false; // idempotent attribute, benign race
-        if (!attr_done) {
-            IFL_HIP(hipFuncSetAttribute((const void *)k_linv_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 96 * 12));
-            attr_done = true;
-        }
+        static LdsOptIn opt_in;
+        if (int rc = lds_opt_in(opt_in, (const void *)k_linv_lds, 96 * 96 * 12)) return rc;
         hipLaunchKernelGGL(k_linv_lds, dim3(1), dim3(256), lds, s, w, linv, g);
     } else {
         const int T = 64;

@@ -61,7 +61,13 @@ template <int C, int KH, int KW> struct DuoCfg {
     static constexpr int THREADS = 128 * NW;
     static constexpr int G = 4 / NW;       // rows per helper wave that start / finish a quad each step
     static constexpr int PF = 8;           // x quads are requested PF steps before their first use
-    static constexpr int PFH = 3;          // mailbox lines are requested PFH steps before they are delivered
+#ifndef IFL_PFH
+#define IFL_PFH 3
+#endif
+    static constexpr int PFH = IFL_PFH;    // mailbox lines are requested PFH steps before they are delivered
+#ifndef IFL_A_VS
+#define IFL_A_VS 4
+#endif
 #ifndef IFL_GATE
 #define IFL_GATE 2
 #endif
@@ -322,7 +328,12 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
 #pragma unroll
                     for (int hl = 0; hl < 2; ++hl) {
                         A[s][q][hl] = Aload[s][q][hl];
-                        asm volatile("" : "+a"(A[s][q][hl]));
+                        // (pinned, or hipcc re-loads the weights inside the loop.  The accumulator half holds 128 registers
+                        // per lane at two waves per SIMD: the low parts of the first IFL_A_VS taps stay in ordinary registers,
+                        // where an MFMA reads them just as well -- left to itself the compiler parks them there anyway and
+                        // copies them into a scratch register in front of every use)
+                        if (NW == 4 && hl == 1 && s < IFL_A_VS) asm volatile("" : "+v"(A[s][q][hl]));
+                        else asm volatile("" : "+a"(A[s][q][hl]));
                     }
         }
         unsigned radr[KH]; // LDS address (slot 0) of this lane's B piece for a source dh rows up
@@ -996,7 +1007,8 @@ static int launch_duo(const float *x, float *z, const void *apack, const Geom &g
 {
     using Cfg = DuoCfg<C, KH, KW>;
     static_assert(Cfg::LDSB <= 160 * 1024, "ring + staging must fit the CU's LDS");
-    IFL_HIP(hipFuncSetAttribute((const void *)k_scan_duo<C, KH, KW, PAD>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDSB));
+    static LdsOptIn opt_in;
+    if (int rc = lds_opt_in(opt_in, (const void *)k_scan_duo<C, KH, KW, PAD>, Cfg::LDSB)) return rc;
     if (scan_general_lds_bytes(g) > (size_t)Cfg::LDSB)
         IFL_FAIL(IFL_EUNSUPPORTED, "launch_scan_duo: fp32 fallback does not fit the kernel's LDS");
     const int nparts = g.H > 16 ? 2 : 1;

@@ -35,12 +35,8 @@ int launch_scan_general(const float *x, const float *wf, float *z, const Geom &g
     if (lds > 160 * 1024)
         IFL_FAIL(IFL_EUNSUPPORTED, "inverse scan: C=%d H=%d K=%dx%d needs %zu B of LDS (> 160 KiB)", g.C, g.H, g.KH,
                  g.KW, lds);
-    static bool attr_done = false; // idempotent attribute, benign race
-    if (!attr_done) {
-        IFL_HIP(hipFuncSetAttribute((const void *)k_scan_general, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024));
-        attr_done = true;
-    }
+    static LdsOptIn opt_in;
+    if (int rc = lds_opt_in(opt_in, (const void *)k_scan_general, 160 * 1024)) return rc;
     hipLaunchKernelGGL(k_scan_general, dim3(g.B), dim3(256), lds, s, x, wf, z, g, rh, rw, gate, rf);
     IFL_HIP(hipGetLastError());
     return IFL_OK;

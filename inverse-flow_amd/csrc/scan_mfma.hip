@@ -44,14 +44,10 @@
 #include "mfma_util.h"
 #include "scan_general_body.h"
 #include <stdlib.h>
-#include <mutex>
-#include <vector>
+
+#include <atomic>
 
 namespace ifl {
-
-// mailbox lines per image and wave of a split scan: the upper half fills line d+8 in step d (d <= W+17), the lower half
-// prefetches line d+27 in step d (d <= W+17: the last ones are never written, nor used); the last line is the verdict
-static constexpr int SPLIT_SLOTS = 80;
 
 template <int C, int KH, int KW, int NTILE> struct ScanCfg {
     static constexpr int NW = C / 16;      // 16-channel output groups
@@ -69,10 +65,7 @@ template <int C, int KH, int KW, int NTILE> struct ScanCfg {
     static constexpr int XROWB = 2 * C * 16 + 16; // quads of one row: [parity][channel][4] + pad (x staging and z staging)
     static constexpr int XSB = 16 * NTILE * XROWB;
     static constexpr int OFF_XS = RINGB, OFF_ZQ = OFF_XS + XSB, OFF_DUMP = OFF_ZQ + XSB;
-    static constexpr int OFF_HALO = OFF_DUMP + 4 * 256 + 64 * NWAVES * 8; // dump: where lanes outside the image write their r (branch-free epilogue)
-    static constexpr int HALOB = 1280; // split scan, lower half: landing zone of one wave's halo granules (4 steps in flight)
-    static constexpr int LDSB = OFF_HALO;
-    static constexpr int LDSB_SPLIT = OFF_HALO + NWAVES * HALOB;
+    static constexpr int LDSB = OFF_DUMP + 4 * 256 + 64 * NWAVES * 8; // dump: where lanes outside the image write their r (branch-free epilogue)
     static constexpr int THREADS = 64 * NWAVES;
     static constexpr int ROWS_PER_ITER = 4 * NTILE; // rows that start/finish a quad each step
     static constexpr int G = ROWS_PER_ITER / NWAVES; // ... per wave: G DMAs and G (possibly masked) stores per step
@@ -107,16 +100,12 @@ __device__ unsigned long long *g_stamps = nullptr;
 
 // PAD: the layer has fewer channels than the instantiation (geom.C < C; the weights are padded with the identity by
 // k_foldpack): lanes beyond geom.C move nothing, their x staging is zero.
-// SPLIT: this workgroup owns one row tile (part 0: rows 0..15, part 1: rows 16..) of image b and hands over / receives
-// the rows in between through the mailbox; returns nonzero when the image has to be redone whole (see k_scan_split).
-template <int C, int KH, int KW, int NTILE, bool PAD, bool SPLIT>
+template <int C, int KH, int KW, int NTILE, bool PAD>
 __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *__restrict__ zout,
                                          const half8 *__restrict__ apack, const int H, const int W, const int rh,
                                          const int rw, int *__restrict__ flags, const float *__restrict__ wf32,
-                                         const Geom &geom, unsigned *__restrict__ amax, const SplitState &sp, const int b,
-                                         const int part, const int skip_plain = 0)
+                                         const Geom &geom, unsigned *__restrict__ amax, const int b)
 {
-    static_assert(!SPLIT || NTILE == 1, "a split scan's workgroup owns one row tile");
     using Cfg = ScanCfg<C, KH, KW, NTILE>;
     constexpr int NQ = Cfg::NQ, NS = Cfg::NS, RBB = Cfg::RBB, SLOTB = Cfg::SLOTB, G = Cfg::G;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -131,8 +120,8 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave index: scalar
     const int wv = wave; // 16-channel output group of this wave
     const int n = lane & 15, g = lane >> 4;
-    const int hoff = SPLIT ? 16 * part : 0;              // first image row of this workgroup
-    const int Hp = SPLIT ? (part ? H - 16 : 16) : H;     // its rows
+    constexpr int hoff = 0;
+    const int Hp = H;
     const int ND = Hp + W - 1;
 
     // ---- zero the r-ring and the zero block (zero padding of the operator) ---------------------------
@@ -210,26 +199,6 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
     // byte offset of the quad (row hr, columns wq..wq+3) in a stored channel plane = gbase + hr*grow + wq*gcol
     const int grow = rh ? -4 * W : 4 * W, gcol = rw ? -4 : 4;
     const int gbase = (rh ? (H - 1) * 4 * W : 0) + (rw ? (W - 4) * 4 : 0) + hoff * grow;
-    // split scan: the last two rows of the upper half travel to the lower half's workgroup through a mailbox in
-    // global memory, as 8-byte {value, tag} granules (two per 16-byte write-through store; the data is the flag:
-    // MI355X hand-off recipe R2).  Lanes n = 14, 15 own them; a wave's 8 lanes fill one 128-byte line per plane set.
-    const unsigned hl8 = (unsigned)(g * 2 + (n & 1)) * 16;
-    const unsigned long long hmask = 0xC000C000C000C000ull;
-    const unsigned hown = n >= 14 ? ~0u : 0u;
-    unsigned epoch = 0;
-    char *mb = nullptr;
-    int dead = 0; // lower half: the upper half never showed up (bounded spin ran out)
-    if constexpr (SPLIT) {
-        epoch = __builtin_amdgcn_readfirstlane(sp.gen[b] + 1);
-        mb = (char *)sp.mbox + ((size_t)b * SPLIT_SLOTS * Cfg::NW + wave) * 256; // [image][step][wave][hi, lo][8 lanes x 16 B]
-    }
-    constexpr int MBSTEP = Cfg::NW * 256;
-    // the mailbox line of the step at hand (upper half: the one it fills, lower half: the one it prefetches), advanced
-    // once per step; the granule registers keep their tags for the whole sweep
-    unsigned long long hline = 0;
-    uintx4 hv0 = {0u, epoch, 0u, epoch}, hv1 = {0u, epoch, 0u, epoch};
-    int p_last = W + 14; // last diagonal with a pixel in row 15 (lower half: set far below once the hand-off is dead)
-
     float rmax = 0.f;       // max |r| this lane put into the ring: beyond the fp16 range the image is redone in fp32
     float zmax = 0.f;       // max |z| this lane stored (handed to the weight-gradient kernel as its prescale)
     int qprev = 0;          // in-row staging offset (parity, position in the quad) of the previous step's column
@@ -263,7 +232,7 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
 #ifdef IFL_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
     unsigned long long st_mask[4] = {0, 0, 0, 0}, st_cnt[4] = {0, 0, 0, 0};
-    unsigned long long st_slow = 0, st_spins = 0, st_rt[4] = {__builtin_amdgcn_s_memrealtime(), 0, 0, 0};
+    unsigned long long st_rt[4] = {__builtin_amdgcn_s_memrealtime(), 0, 0, 0};
     const unsigned long long st_begin = st_last;
 #endif
     __syncthreads();
@@ -296,39 +265,8 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
         ro_loff = ro_lds + __mul24(hr, Cfg::XROWB) + ((wq >> 2) & 1) * (C * 16);
         ro_okm = ok ? -1 : 0;
     };
-    // PART: -1 = the whole image in this workgroup; 0 / 1 = upper / lower half of a split scan
-    auto halo_slow = [&](const int d, uintx4 &q0, uintx4 &q1) {
-        // the granules prefetched three steps ago were not there yet: poll them (bounded) with agent-scope loads
-        const unsigned long long *hp = (const unsigned long long *)(mb + (size_t)(d + 24) * MBSTEP + hl8);
-#ifdef IFL_STAMPS
-        st_slow += 1;
-#endif
-        for (int spins = 0;; ++spins) {
-#ifdef IFL_STAMPS
-            st_spins += 1;
-#endif
-            unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-            if (n >= 14) {
-                a0 = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                a1 = __hip_atomic_load(hp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                a2 = __hip_atomic_load(hp + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                a3 = __hip_atomic_load(hp + 17, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            q0 = uintx4{(unsigned)a0, (unsigned)(a0 >> 32), (unsigned)a1, (unsigned)(a1 >> 32)};
-            q1 = uintx4{(unsigned)a2, (unsigned)(a2 >> 32), (unsigned)a3, (unsigned)(a3 >> 32)};
-            const bool ok = n < 14 || (q0[1] == epoch && q0[3] == epoch && q1[1] == epoch && q1[3] == epoch);
-            if (__all(ok)) break;
-            if (spins > 20000) { // ~tens of ms: the image is flagged and redone whole by the sweep behind this launch
-                dead = 1;
-                p_last = -1000;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
-    };
-    auto step = [&](auto mask_c, auto scaled_c, auto part_c, const int d) {
+    auto step = [&](auto mask_c, auto scaled_c, const int d) {
         constexpr int MASK = decltype(mask_c)::value;
-        constexpr int PART = decltype(part_c)::value;
         constexpr bool SCALED = decltype(scaled_c)::value; // a retry with x scaled down (see the sweep below)
         constexpr int NA = (MASK & 1) + ((MASK >> 1) & 1);
         constexpr int NDH = KH < 2 ? KH : 2;
@@ -351,8 +289,7 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
         // the DMA of step d-3 -- with stores in flight it also asks for a DMA that is two steps old, which has
         // landed long ago -- and never waits for a store of the previous step (a store takes ~2 us to retire).
         // Then the barrier: r of diagonal d-1 and the z staged in step d-1 are complete in LDS.
-        // (split scan: plus the two mailbox operations per step, which follow the DMAs in program order)
-        wait_vm_then_barrier<(PART == 0 ? 2 * G + 6 : PART == 1 ? 2 * G + 4 : 2 * G)>();
+        wait_vm_then_barrier<2 * G>();
         IFL_STAMP(1); // wait + barrier
 
         // in-row staging offset of this step's column w = d - h: the same for all tiles (rows 16 apart)
@@ -365,10 +302,6 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
         floatx4_ sv[G];
         floatx2 xq[NTILE][2];
         half8 Fh[NTILE][2][NQ], Fl[NTILE][2][NQ];
-        // lower half: the halo granules that landed for this step are read behind the dh=2 fragments (two MFMAs of the
-        // first critical group have no request to carry) and used at the end of the step
-        constexpr int NHQ = (PART == 1 && MASK != 0) ? 2 : 0;
-        floatx4_ hq[2];
         constexpr int NREQ = G + (MASK != 0 ? 2 * NA + NDH * PER : 0);
         auto request = [&](int j) {
             int c = 0;
@@ -515,43 +448,6 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
                              : "memory", "scc", "m0");
             }
         };
-        // ---- chunk: mailbox operations of a split scan (always two per step: the wait above counts them) -----------
-        //   upper half: rows 14, 15 of r_d as {value, tag} granules, write-through (zero outside the image: padding)
-        //   lower half: LDS-DMA of the granules of diagonal d+3 (one line per plane set, read once per launch, so a
-        //               stale L1 copy cannot exist; a granule that is not there yet fails its tag check)
-        auto halo_store = [&](const uintx2 hb, const uintx2 lb) {
-            hv0[0] = hb[0];
-            hv0[2] = hb[1];
-            hv1[0] = lb[0];
-            hv1[2] = lb[1];
-            unsigned long long saved;
-            asm volatile("s_mov_b64 %0, exec\n\t"
-                         "s_and_b64 exec, exec, %3\n\t"
-                         "global_store_dwordx4 %4, %1, %5 sc0 sc1\n\t"
-                         "global_store_dwordx4 %4, %2, %5 offset:128 sc0 sc1\n\t"
-                         "s_mov_b64 exec, %0\n\t"
-                         "s_nop 1"
-                         : "=&s"(saved), "+v"(hv0), "+v"(hv1)
-                         : "s"(hmask), "v"(hl8), "s"(hline)
-                         : "memory", "scc");
-        };
-        auto chunk_halo = [&]() {
-            if constexpr (PART == 1) {
-                const unsigned dst = __builtin_amdgcn_readfirstlane(ldsbase + Cfg::OFF_HALO + wave * Cfg::HALOB + ((d + 3) & 3) * 32);
-                unsigned long long saved;
-                asm volatile("s_mov_b32 m0, %1\n\t"
-                             "s_mov_b64 %0, exec\n\t"
-                             "s_and_b64 exec, exec, %2\n\t"
-                             "global_load_lds_dwordx4 %3, %4 sc0 sc1\n\t"
-                             "global_load_lds_dwordx4 %3, %4 offset:128 sc0 sc1\n\t"
-                             "s_mov_b64 exec, %0"
-                             : "=&s"(saved)
-                             : "s"(dst), "s"(hmask), "v"(hl8), "s"(hline)
-                             : "memory", "scc", "m0");
-            } else if constexpr (PART == 0 && MASK == 0) {
-                halo_store(uintx2{0u, 0u}, uintx2{0u, 0u}); // (no diagonal finished: keeps the operation count per step)
-            }
-        };
         // ---- chunk: epilogue of tile T (the chain): r_d = x + acc[0] -> split fp16 -> ring; then the accumulators
         //      rotate: diagonal d+1 becomes the head, a fresh one joins for d+3 -------------------------------
         auto chunk_epilogue = [&](int T) {
@@ -574,12 +470,6 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
             *(half4 *)(rp + 4 * 256) = lo;
             const float m = fmaxf(fmaxf(fabsf(rv[0]), fabsf(rv[1])), fmaxf(fabsf(rv[2]), fabsf(rv[3])));
             rmax = valid ? fmaxf(rmax, m) : rmax;
-            if constexpr (PART == 0) {
-                // (zero outside the image: the operator's padding; an AND, not a select: no branch in this chunk)
-                const uintx2 hb = __builtin_bit_cast(uintx2, hi), lb = __builtin_bit_cast(uintx2, lo);
-                const unsigned vm = valid ? ~0u : 0u;
-                halo_store(uintx2{hb[0] & vm, hb[1] & vm}, uintx2{lb[0] & vm, lb[1] & vm});
-            }
         };
 
         using N0 = std::integral_constant<int, 0>;
@@ -592,7 +482,6 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
             chunk_store();
 #pragma unroll
             for (int i = 0; i < G; ++i) chunk_dma(i);
-            chunk_halo();
             ro_stage(d + 1);
             fence();
         } else {
@@ -620,7 +509,6 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
                 if constexpr (KH < 2) {
 #pragma unroll
                     for (int i = 0; i < G; ++i) chunk_dma(i);
-            chunk_halo();
                 }
                 weave(std::integral_constant<int, 2>{}, N0{}, NGM{}, std::integral_constant<int, 3>{});
             } else {
@@ -630,14 +518,12 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
                 chunk_store();
 #pragma unroll
                 for (int i = 0; i < G; ++i) chunk_dma(i);
-            chunk_halo();
                 fence();
             }
             IFL_STAMP(2); // read issue + leading MFMAs (+ all reads landed, when stamping)
             // ---- critical: taps (0,1) and (1,0) of r_{d-1} -> diagonal d -----------------------------------------
             // The dh=2 fragments of r_{d-1} (next step's leading operands; single-buffered: every MFMA that reads the
             // old ones has been issued) are requested between the first critical MFMAs.
-            const unsigned hqa = ldsbase + Cfg::OFF_HALO + wave * Cfg::HALOB + (d & 3) * 32 + lane * 16;
             auto request2 = [&](int j) {
                 int c = 0;
 #pragma unroll
@@ -663,22 +549,17 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
                             if (MASK & (1 << T)) asm volatile("" : "+a"(ahi[T][0]), "+a"(amid[T][0]));
                         fence();
                         if (k < PER) request2(k);
-                        if constexpr (NHQ) {
-                            if (k == PER || (k == GM - 1 && PER >= GM)) lds_read_f32x4(hq[0], hqa);
-                            if (k == PER + 1 || (k == GM - 1 && PER + 1 >= GM)) lds_read_f32x4(hq[1], hqa + 128);
-                        }
                         fence();
                     }
                 }
                 fence();
             }
             if constexpr (KH > 1) {
-                lgkm_wait_n(NRD2 + (KH > 2 ? NHQ : 0)); // ... and the dh=1 fragments
+                lgkm_wait_n(NRD2); // ... and the dh=1 fragments
                 mf(KW, f1h, f1l, 1, 0);
                 if constexpr (KH > 2) { // (the DMA issue rides here: the last leading group already carries the stores)
 #pragma unroll
                     for (int i = 0; i < G; ++i) chunk_dma(i);
-            chunk_halo();
                     weave(std::integral_constant<int, 7>{}, N0{}, NGM{}, std::integral_constant<int, 2>{});
                 } else {
                     fence();
@@ -772,43 +653,7 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
             IFL_STAMP(5); // trailing MFMAs issued
         }
 
-        if constexpr (NHQ) {
-            // lower half: rows 14, 15 of the upper half's diagonal d+16 join this step's r in the ring (row block 0)
-            if (d + 16 <= p_last) {
-                if constexpr (KH <= 2) { // (no dh=2 group to ride on)
-                    const unsigned hqa = ldsbase + Cfg::OFF_HALO + wave * Cfg::HALOB + (d & 3) * 32 + lane * 16;
-                    lds_read_f32x4(hq[0], hqa);
-                    lds_read_f32x4(hq[1], hqa + 128);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hq[0]), "+v"(hq[1])::"memory");
-                uintx4 q0 = __builtin_bit_cast(uintx4, hq[0]), q1 = __builtin_bit_cast(uintx4, hq[1]);
-                // all four tags against this launch's, on the vector unit (the compiler turns the plain expression into
-                // four compares and a chain of scalar ORs: twice the issue time)
-                unsigned miss, mt;
-                asm("v_xor_b32 %0, %2, %6\n\t"
-                    "v_xor_b32 %1, %3, %6\n\t"
-                    "v_or_b32 %0, %0, %1\n\t"
-                    "v_xor_b32 %1, %4, %6\n\t"
-                    "v_or_b32 %0, %0, %1\n\t"
-                    "v_xor_b32 %1, %5, %6\n\t"
-                    "v_or_b32 %0, %0, %1\n\t"
-                    "v_and_b32 %0, %0, %7"
-                    : "=&v"(miss), "=&v"(mt)
-                    : "v"(q0[1]), "v"(q0[3]), "v"(q1[1]), "v"(q1[3]), "s"(epoch), "v"(hown));
-                if (__any(miss != 0)) halo_slow(d, q0, q1);
-                unsigned char *hp = ring + dstoff + wadr[0] - RBB; // (lanes n < 14 write rows nobody reads)
-                *(unsigned *)hp = q0[0];
-                *(unsigned *)(hp + 4) = q0[2];
-                *(unsigned *)(hp + 4 * 256) = q1[0];
-                *(unsigned *)(hp + 4 * 256 + 4) = q1[2];
-            }
-        }
-        if constexpr (PART >= 0) hline += MBSTEP;
         qprev = qcur;
-#ifdef IFL_STAMPS
-        if (PART == 0 && d == 18) st_rt[3] = __builtin_amdgcn_s_memrealtime();
-        if (PART == 1 && d == -5) st_rt[3] = st_entry;
-#endif
         IFL_STAMP(6); // bookkeeping
 #ifdef IFL_STAMPS
         st_mask[MASK] += st_last - st_t0;
@@ -820,68 +665,39 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
     // the step after its last one (the z product of the last diagonal): the sets of active tiles come in the
     // order {}, {0}, {0,1}, {1}, {} -- one loop per set, so that no control flow merges inside a step.  The last
     // step stores the quads staged by the one before.
-    auto sweep = [&](auto scaled_c, auto part_c) {
+    auto sweep = [&](auto scaled_c) {
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
         const int last0 = (15 + W - 1 < ND - 1 ? 15 + W - 1 : ND - 1) + 1; // last step of tile 0
-        // (the lower half of a split scan starts two steps early: its first halo granules are due at step -2 and
-        // are requested three steps ahead)
-        int d = decltype(part_c)::value == 1 ? -5 : -3;
-        if constexpr (decltype(part_c)::value == 0) hline = (unsigned long long)(mb + (size_t)(d + 8) * MBSTEP);
-        if constexpr (decltype(part_c)::value == 1) hline = (unsigned long long)(mb + (size_t)(d + 27) * MBSTEP);
+        int d = -3;
         ro_stage(d);
-        for (; d < -2; ++d) step(I0{}, scaled_c, part_c, d);
+        for (; d < -2; ++d) step(I0{}, scaled_c, d);
         if constexpr (NTILE == 2) {
             using I2 = std::integral_constant<int, 2>;
             using I3 = std::integral_constant<int, 3>;
-            for (; d < 14; ++d) step(I1{}, scaled_c, part_c, d);
-            for (; d <= last0; ++d) step(I3{}, scaled_c, part_c, d);
-            for (; d <= ND; ++d) step(I2{}, scaled_c, part_c, d);
+            for (; d < 14; ++d) step(I1{}, scaled_c, d);
+            for (; d <= last0; ++d) step(I3{}, scaled_c, d);
+            for (; d <= ND; ++d) step(I2{}, scaled_c, d);
         } else {
-            for (; d <= last0; ++d) step(I1{}, scaled_c, part_c, d);
+            for (; d <= last0; ++d) step(I1{}, scaled_c, d);
         }
-        for (; d <= ND + 2; ++d) step(I0{}, scaled_c, part_c, d);
+        for (; d <= ND + 2; ++d) step(I0{}, scaled_c, d);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every DMA and store of the sweep has retired
     };
-    using PWhole = std::integral_constant<int, -1>;
-    if constexpr (SPLIT) {
-        if (part == 0) {
-#ifdef IFL_STAMPS
-            st_rt[1] = __builtin_amdgcn_s_memrealtime();
-#endif
-            sweep(std::false_type{}, std::integral_constant<int, 0>{});
-        } else {
-            // Gate: start once the upper half's diagonal 14 + GATE is visible.  Every prefetch (three steps ahead) then
-            // finds its granules; without the gate the first ones are requested before they exist and each costs a
-            // round of polling (measured: 7 episodes, 30k cycles).
-            constexpr int GATE = 3;
-            uintx4 q0, q1;
-            halo_slow(GATE - 2, q0, q1);
-#ifdef IFL_STAMPS
-            st_rt[1] = __builtin_amdgcn_s_memrealtime();
-#endif
-            sweep(std::false_type{}, std::integral_constant<int, 1>{});
-        }
-    } else {
-        // (skip_plain: the caller knows that the plain sweep leaves the fp16 range -- the redo of a split scan)
-        if (!skip_plain) sweep(std::false_type{}, PWhole{});
-    }
+    sweep(std::false_type{});
 
 #ifdef IFL_STAMPS
-    // (the redo sweep behind a split launch never gets here for image 0 unless it was flagged)
     if (g_stamps && b == 0 && lane == 0)
-        for (int k = 0; k < 8; ++k) g_stamps[part * 80 + wave * 8 + k] = st_acc[k];
+        for (int k = 0; k < 8; ++k) g_stamps[wave * 8 + k] = st_acc[k];
     if (g_stamps && b == 0 && lane == 0 && wave == 0) {
         for (int k = 0; k < 4; ++k) {
-            g_stamps[part * 80 + 64 + k] = st_mask[k];
-            g_stamps[part * 80 + 68 + k] = st_cnt[k];
+            g_stamps[64 + k] = st_mask[k];
+            g_stamps[68 + k] = st_cnt[k];
         }
         st_rt[2] = __builtin_amdgcn_s_memrealtime();
-        for (int k = 0; k < 4; ++k) g_stamps[part * 80 + 72 + k] = st_rt[k];
-        g_stamps[part * 80 + 76] = st_slow;
-        g_stamps[part * 80 + 77] = st_spins;
-        g_stamps[part * 80 + 78] = st_begin;
-        g_stamps[part * 80 + 79] = __builtin_amdgcn_s_memtime();
+        for (int k = 0; k < 4; ++k) g_stamps[72 + k] = st_rt[k];
+        g_stamps[78] = st_begin;
+        g_stamps[79] = __builtin_amdgcn_s_memtime();
     }
 #endif
     // Split fp16 cannot hold |r| >= 65504, and a badly conditioned operator grows r along the sweep.  Such an image
@@ -892,44 +708,7 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
     // is not finite, the exact fp32 body takes over (general scan body, right-fold form, fp32 copy of the same folded
     // weights): slow, but never a silent Inf/NaN where the exact solver is finite.  flags[] records what happened
     // (diagnostics only: 0, 1 = rescaled, +4 = fp32).
-    if constexpr (SPLIT) {
-        // A half that left the fp16 range (or lost its partner) makes the image void: the lower half's workgroup then
-        // redoes it whole (scaled retry, fp32 body).  The upper half tells it through a verdict granule; if its own
-        // rows are void it first writes its L2's dirty lines back (agent-scope release), so that they cannot land on
-        // top of the redone rows later (the two workgroups may sit on XCDs with separate L2s).
-        // bit 0: left the fp16 range; bit 1: the hand-off failed
-        int bad = __syncthreads_or((rmax < 6.0e4f ? 0 : 1) | (dead << 1)); // (every wave is behind its vmcnt(0): sweep end)
-        if (amax) {
-            for (int o = 32; o > 0; o >>= 1) zmax = fmaxf(zmax, __shfl_down(zmax, o, 64));
-            if (lane == 0) atomicMax(amax, __float_as_uint(zmax));
-        }
-        unsigned long long *verdict = (unsigned long long *)((char *)sp.mbox + (size_t)b * SPLIT_SLOTS * MBSTEP + (SPLIT_SLOTS - 1) * MBSTEP);
-        if (part == 0) {
-            if (tid == 0) {
-                if (bad) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                __hip_atomic_store(verdict, ((unsigned long long)epoch << 32) | (unsigned)(bad ? 2 : 1), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            }
-        } else {
-            // (the upper half finished some twenty steps ago: one poll in practice; bounded all the same)
-            unsigned pv = 0;
-            for (int spins = 0; spins < 20000; ++spins) {
-                const unsigned long long v = __hip_atomic_load(verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned)(v >> 32) == epoch) {
-                    pv = (unsigned)v;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            bad |= pv == 1 ? 0 : (pv == 2 ? 1 : 2); // (no verdict in time counts as a failed hand-off)
-            bad = __syncthreads_or(bad);
-        }
-        return bad;
-    } else {
-    int redo = skip_plain ? 1 : __syncthreads_or(rmax < 6.0e4f ? 0 : 1);
+    int redo = __syncthreads_or(rmax < 6.0e4f ? 0 : 1);
     int attempts = 0;
     while (redo && attempts < 1) {
         ++attempts;
@@ -958,7 +737,7 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
         zmax = 0.f;
         qprev = 0;
         __syncthreads();
-        sweep(std::true_type{}, PWhole{});
+        sweep(std::true_type{});
         redo = __syncthreads_or(rmax < 6.0e4f ? 0 : 1);
     }
     if (tid == 0) flags[b] = attempts + (redo ? 4 : 0); // every workgroup owns its word: no clearing pass needed
@@ -975,7 +754,6 @@ __device__ __forceinline__ int scan_body(const float *__restrict__ xin, float *_
         for (int o = 32; o > 0; o >>= 1) zmax = fmaxf(zmax, __shfl_down(zmax, o, 64));
         if (lane == 0) atomicMax(amax, __float_as_uint(zmax)); // one atomic per wave; max is order-independent
     }
-    } // !SPLIT
     return 0;
 }
 
@@ -985,39 +763,7 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_scan_mfma(const float *__rest
                                                              int *__restrict__ flags, const float *__restrict__ wf32,
                                                              Geom geom, unsigned *__restrict__ amax)
 {
-    const SplitState none{nullptr, nullptr};
-    scan_body<C, KH, KW, NTILE, PAD, false>(xin, zout, apack, H, W, rh, rw, flags, wf32, geom, amax, none, (int)blockIdx.x, 0);
-}
-
-// Split scan (16 < H <= 32, at most half as many images as compute units): two workgroups per image, one row tile
-// each.  The both-tiles steps of the whole-image kernel (3260 cycles) become one-tile steps (~2100) on twice the
-// compute units; the lower half runs 14 + 4.5 diagonals behind the upper one (dependency + hand-off).  Workgroups
-// i and i+8 pair up (the same XCD under the observed round-robin placement: speed only); the upper half has the
-// lower index and never waits for anybody, so the pair cannot deadlock whatever the dispatch order does; every
-// spin of the lower half is bounded, and an image whose hand-off failed is simply redone whole.
-template <int C, int KH, int KW, bool PAD>
-__global__ __launch_bounds__(64 * (C / 16)) void k_scan_split(const float *__restrict__ xin, float *__restrict__ zout,
-                                                              const half8 *__restrict__ apack, int H, int W, int rh, int rw,
-                                                              int *__restrict__ flags, const float *__restrict__ wf32,
-                                                              Geom geom, unsigned *__restrict__ amax, SplitState sp)
-{
-    const int b = (int)((blockIdx.x >> 4) * 8 + (blockIdx.x & 7));
-    const int part = (blockIdx.x >> 3) & 1;
-    if (b >= geom.B) return;
-    const int bad = scan_body<C, KH, KW, 1, PAD, true>(xin, zout, apack, H, W, rh, rw, flags, wf32, geom, amax, sp, b, part);
-    if (part == 0) return;
-    if (bad) {
-        __syncthreads();
-        // (void because of the range only: straight to the scaled sweep)
-        scan_body<C, KH, KW, 2, PAD, false>(xin, zout, apack, H, W, rh, rw, flags, wf32, geom, amax, sp, b, 0, bad == 1);
-    } else if (threadIdx.x == 0) {
-        flags[b] = 0;
-    }
-    // the next launch uses another tag (both halves have read this one long ago; gen + 1 is never 0)
-    if (threadIdx.x == 0) {
-        const unsigned gnext = sp.gen[b] + 1;
-        sp.gen[b] = gnext == 0xFFFFFFFFu ? 0u : gnext;
-    }
+    scan_body<C, KH, KW, NTILE, PAD>(xin, zout, apack, H, W, rh, rw, flags, wf32, geom, amax, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1305,65 +1051,18 @@ int launch_foldpack_mfma(const float *w, void *out0, float *wf0, void *out1, flo
     return launch_foldpack_jobs(jobs, 1, ndir, s);
 }
 
-// ---- split-scan state: a caller-owned, zero-initialised block per (device, stream), registered with
-//      ifl_scan_state_register (the library never allocates: without a registered block the whole-image kernel runs).
-// Layout: [generation per image, 128 words] [mailbox: 128 images x 80 steps x 4 waves x 256 B; the last step = verdict].
-// Tags are per-image launch generations, so the mailbox needs no cleaning between launches; generations advance on
-// the device (the lower half's last act), which keeps the scheme valid under graph replay.
-namespace {
-constexpr int SPLIT_MAX_IMAGES = 128;
-constexpr size_t SPLIT_MBOX_OFF = SPLIT_MAX_IMAGES * sizeof(unsigned);
-constexpr size_t SPLIT_BYTES = SPLIT_MBOX_OFF + (size_t)SPLIT_MAX_IMAGES * SPLIT_SLOTS * 4 * 256;
-struct SplitBlock {
-    int dev;
-    hipStream_t stream;
-    char *ptr;
-};
-std::mutex g_split_mu;
-std::vector<SplitBlock> g_split_blocks; // (pointers to caller-owned memory, nothing else)
-} // namespace
-
-size_t scan_state_bytes() { return SPLIT_BYTES; }
-
-int scan_state_register(void *state, size_t bytes, hipStream_t s)
-{
-    int dev = 0;
-    IFL_HIP(hipGetDevice(&dev));
-    if (state && bytes < SPLIT_BYTES) IFL_FAIL(IFL_EWORKSPACE, "ifl_scan_state_register: %zu bytes needed, %zu given", SPLIT_BYTES, bytes);
-    if (state && ((uintptr_t)state & 255)) IFL_FAIL(IFL_EINVAL, "ifl_scan_state_register: the block must be 256-byte aligned");
-    std::lock_guard<std::mutex> lock(g_split_mu);
-    for (size_t i = 0; i < g_split_blocks.size(); ++i)
-        if (g_split_blocks[i].dev == dev && g_split_blocks[i].stream == s) {
-            if (state) g_split_blocks[i].ptr = (char *)state;
-            else g_split_blocks.erase(g_split_blocks.begin() + (long)i);
-            return IFL_OK;
-        }
-    if (state) g_split_blocks.push_back(SplitBlock{dev, s, (char *)state});
-    return IFL_OK;
-}
-
-// the block registered for this device and stream, or nullptr
-static char *split_state(hipStream_t s)
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(g_split_mu);
-    for (const SplitBlock &e : g_split_blocks)
-        if (e.dev == dev && e.stream == s) return e.ptr;
-    return nullptr;
-}
-
+// compute units of the current device (a cache of a device property: written once per device, with its final value)
 static int device_cus()
 {
-    static int cus[64] = {0};
+    static std::atomic<int> cus[IFL_MAX_DEVICES];
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    if (!cus[dev]) {
-        int v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= IFL_MAX_DEVICES) return 0;
+    int v = cus[dev].load(std::memory_order_relaxed);
+    if (!v) {
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        cus[dev] = v;
+        cus[dev].store(v, std::memory_order_relaxed);
     }
-    return cus[dev];
+    return v;
 }
 
 template <int C, int KH, int KW, int NTILE, bool PAD>
@@ -1372,12 +1071,8 @@ static int launch_one(const float *x, float *z, const void *apack, const Geom &g
 {
     using Cfg = ScanCfg<C, KH, KW, NTILE>;
     static_assert(Cfg::LDSB <= 160 * 1024, "ring + x staging must fit the CU's LDS");
-    static bool attr_done = false; // idempotent attribute, benign race
-    if (!attr_done) {
-        IFL_HIP(hipFuncSetAttribute((const void *)k_scan_mfma<C, KH, KW, NTILE, PAD>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDSB));
-        attr_done = true;
-    }
+    static LdsOptIn opt_in;
+    if (int rc = lds_opt_in(opt_in, (const void *)k_scan_mfma<C, KH, KW, NTILE, PAD>, Cfg::LDSB)) return rc;
     if (scan_general_lds_bytes(g) > (size_t)Cfg::LDSB)
         IFL_FAIL(IFL_EUNSUPPORTED, "launch_scan_mfma: fp32 fallback does not fit the kernel's LDS");
 #ifdef IFL_STAMPS
@@ -1394,20 +1089,19 @@ static int launch_one(const float *x, float *z, const void *apack, const Geom &g
 }
 
 int launch_scan_mfma(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, int *flags,
-                     const float *wf32, unsigned *amax, hipStream_t s)
+                     const float *wf32, unsigned *amax, void *state, bool whole_image, hipStream_t s)
 {
     const int nt = g.H <= 16 ? 1 : 2;
     const int ct = mfma_padded_channels(g.C);
-    {
-        // bring-up switch (IFL_DUO=0: the round-1 kernels)
-        const char *e = getenv("IFL_DUO");
-        const bool duo = !(e && atoi(e) == 0) && scan_duo_supported(g);
-        const char *ns = getenv("IFL_NO_SPLIT");
-        const bool no_split = ns && atoi(ns);
-        if (duo && nt == 1) return launch_scan_duo(x, apack, z, g, rh, rw, flags, wf32, amax, nullptr, s);
-        char *st = nullptr;
-        if (duo && nt == 2 && !no_split && g.B <= scan_duo_max_images() && 2 * g.B <= device_cus() && (st = split_state(s)))
-            return launch_scan_duo(x, apack, z, g, rh, rw, flags, wf32, amax, st, s);
+    // Layers of exactly 32 or 64 channels on 32-pixel rows: the duo form (scan_duo.hip), one workgroup per 16-row tile --
+    // an image of more than 16 rows is two workgroups, which needs the caller's scan-state block and a compute unit per
+    // workgroup.  Everything else: one workgroup per image, below.
+    if (scan_duo_supported(g)) {
+        if (nt == 1) return launch_scan_duo(x, apack, z, g, rh, rw, flags, wf32, amax, nullptr, s);
+        if (state && !whole_image && g.B <= scan_duo_max_images() && 2 * g.B <= device_cus()) {
+            if ((uintptr_t)state & 255) IFL_FAIL(IFL_EINVAL, "scan_state must be 256-byte aligned");
+            return launch_scan_duo(x, apack, z, g, rh, rw, flags, wf32, amax, state, s);
+        }
     }
 #define IFL_CASE(CC, KK, NN) \
     if (ct == CC && g.KH == KK && g.KW == KK && nt == NN)                                                                   \

@@ -553,12 +553,8 @@ static int launch_wg(const float *a, const float *bb, float *partial, const unsi
     const int nsplit = (ntask + 3) / 4;
     constexpr int NB = C / 32;
     const size_t lds = (size_t)2 * KH * KW * 4 * 64 * sizeof(floatx4);
-    static bool attr_done = false; // idempotent attribute, benign race
-    if (!attr_done) {
-        IFL_HIP(hipFuncSetAttribute((const void *)k_wgrad_mfma<C, KH, KW, NKS, CEN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
-        attr_done = true;
-    }
+    static LdsOptIn opt_in;
+    if (int rc = lds_opt_in(opt_in, (const void *)k_wgrad_mfma<C, KH, KW, NKS, CEN>, (int)lds)) return rc;
 #ifdef IFL_STAMPS
     if (const char *e = getenv("IFL_WSTAMPS")) {
         unsigned long long *ptr = (unsigned long long *)strtoull(e, nullptr, 0);

@@ -17,6 +17,7 @@ ORDERS = {"TL": 0, "TR": 1, "BL": 2, "BR": 3}
 FLAG_GENERAL_DIAG = 1
 FLAG_EXACT_F32 = 2
 FLAG_NO_MFMA = 4
+FLAG_WHOLE_IMAGE = 8
 OP_INVERSE, OP_FORWARD, OP_BACKWARD, OP_DY, OP_DW = range(5)
 
 _lib = None
@@ -30,15 +31,14 @@ SIGNATURES = {
     "ifl_profile_enable": (None, [_i]),
     "ifl_profile_collect": (_i, [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i)]),
     "ifl_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _u]),
-    "ifl_inverse_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp]),
+    "ifl_inverse_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp, _vp]),
     "ifl_unit_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _u]),
-    "ifl_unit_inverse_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp]),
-    "ifl_unit_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp]),
+    "ifl_unit_inverse_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp, _vp]),
+    "ifl_unit_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp, _vp]),
     "ifl_carry_bytes": (_sz, [_i, _i, _i]),
     "ifl_scan_state_bytes": (_sz, []),
-    "ifl_scan_state_register": (_i, [_vp, _sz, _vp]),
     "ifl_forward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
-    "ifl_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp]),
+    "ifl_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp, _vp]),
     "ifl_dw_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "ifl_conv2d_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ifl_conv2d_wgrad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
@@ -178,27 +178,28 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-# Persistent state of the split scan (include/invflow.h, ifl_scan_state_register): the library never allocates, so
-# this host layer owns one zero-filled block per (device, stream) and registers it on the stream's first scan.
+# Persistent block of the two-workgroup scan (include/invflow.h, ifl_scan_state_bytes): an argument of every scan call.  The
+# library never allocates, so this host layer owns one zero-filled block per (device, stream): launches that share a block
+# must not overlap, and launches of one stream do not.
 _scan_states = {}
 
 
-def _ensure_scan_state(dev):
-    """Register the split-scan block of the current stream of `dev` (no-op after the first call; skipped while the
-    stream is being captured: the whole-image kernel is used then unless the block exists already)."""
+def scan_state(dev):
+    """The block of the current stream of `dev`, or None while a stream without one is being captured (the scan then runs
+    one workgroup per image: same bits)."""
     stream = _raw_stream()  # (called under the device guard: the current device is `dev`)
     key = (torch.cuda.current_device(), stream)
-    if key in _scan_states:
-        return
+    st = _scan_states.get(key)
+    if st is not None:
+        return st
     if torch.cuda.is_current_stream_capturing():
-        return
-    L = lib()
-    nb = int(L.ifl_scan_state_bytes())
+        return None
+    nb = int(lib().ifl_scan_state_bytes())
     with _on(dev):
         st = torch.zeros(nb, dtype=torch.uint8, device=dev)
         torch.cuda.current_stream(dev).synchronize()  # (the zero fill is complete before any launch can see the block)
-        _check(L.ifl_scan_state_register(_ptr(st), nb, stream), "ifl_scan_state_register")
     _scan_states[key] = st
+    return st
 
 
 def new_carry(w):
@@ -223,11 +224,10 @@ def inverse(x, w, order="TL", flags=0, out=None, carry=None):
     dev = _same_device(x, w, out)
     L = lib()
     with _on(dev):
-        _ensure_scan_state(dev)
         nb = L.ifl_workspace_bytes(OP_INVERSE, B, C, H, W, KH, KW, flags)
         ws = _ws(nb, dev)
         rc = L.ifl_inverse_f32(_ptr(x), _ptr(w), _ptr(out), B, C, H, W, KH, KW, _order(order), flags, _ptr(ws), nb,
-                               _ptr(carry), _raw_stream())
+                               _ptr(carry), _ptr(scan_state(dev)), _raw_stream())
     _check(rc, "ifl_inverse_f32")
     return out
 
@@ -256,13 +256,12 @@ def unit_inverse(x, ws4, flags=0, carries=None):
     zs = [torch.empty_like(x) for _ in range(4)]
     L = lib()
     with _on(dev):
-        _ensure_scan_state(dev)
         nb = L.ifl_unit_workspace_bytes(OP_INVERSE, B, C, H, W, KH, KW, flags)
         ws = _ws(nb, dev)
         wp, zp = _ptr4(ws4), _ptr4(zs)
         cp = _ptr4(carries) if carries is not None else None
         rc = L.ifl_unit_inverse_f32(_ptr(x), wp, zp, B, C, H, W, KH, KW, flags, _ptr(ws), nb, cp,
-                                    _raw_stream())
+                                    _ptr(scan_state(dev)), _raw_stream())
     _check(rc, "ifl_unit_inverse_f32")
     return zs
 
@@ -276,12 +275,11 @@ def unit_backward(g, zs, ws4, flags=0, carries=None):
     dws = [torch.empty_like(w) for w in ws4]
     L = lib()
     with _on(dev):
-        _ensure_scan_state(dev)
         nb = L.ifl_unit_workspace_bytes(OP_BACKWARD, B, C, H, W, KH, KW, flags)
         ws = _ws(nb, dev)
         cp = _ptr4(carries) if carries is not None else None
         rc = L.ifl_unit_backward_f32(_ptr(g), _ptr4(zs), _ptr4(ws4), _ptr(dx), _ptr4(dws), B, C, H, W, KH, KW, flags,
-                                     _ptr(ws), nb, cp, _raw_stream())
+                                     _ptr(ws), nb, cp, _ptr(scan_state(dev)), _raw_stream())
     _check(rc, "ifl_unit_backward_f32")
     return dx, dws
 
@@ -338,7 +336,6 @@ def backward(g, z, w, order="TL", flags=0, x=None, recon_weight=0.0, need_dx=Tru
     rl = torch.zeros(1, dtype=torch.float32, device=dev) if recon else None
     L = lib()
     with _on(dev):
-        _ensure_scan_state(dev)
         nb = L.ifl_workspace_bytes(OP_BACKWARD, B, C, H, W, KH, KW, flags)
         if need_dx and not recon:  # no activation-sized temporaries needed: fold (+ dW partials)
             nb = L.ifl_workspace_bytes(OP_DY, B, C, H, W, KH, KW, flags)
@@ -347,7 +344,7 @@ def backward(g, z, w, order="TL", flags=0, x=None, recon_weight=0.0, need_dx=Tru
         ws = _ws(nb, dev)
         rc = L.ifl_backward_f32(_ptr(g), _ptr(z) if need_dw else None, _ptr(x) if recon else None, _ptr(w), _ptr(dx),
                                 _ptr(dw), float(recon_weight) if recon else 0.0, _ptr(rl), B, C, H, W, KH, KW,
-                                _order(order), flags, _ptr(ws), nb, _ptr(carry),
+                                _order(order), flags, _ptr(ws), nb, _ptr(carry), _ptr(scan_state(dev)),
                                 _raw_stream())
     _check(rc, "ifl_backward_f32")
     return dx, dw, rl

@@ -54,16 +54,16 @@ def test_version_and_workspace(H):
 def test_argument_validation_without_gpu(H):
     L = H.lib()
     # bad shape -> IFL_EINVAL with a message, nothing is launched
-    rc = L.ifl_inverse_f32(None, None, None, 2, 0, 5, 5, 3, 3, 0, 0, None, 0, None, None)
+    rc = L.ifl_inverse_f32(None, None, None, 2, 0, 5, 5, 3, 3, 0, 0, None, 0, None, None, None)
     assert rc == -1 and b"bad shape" in L.ifl_last_error()
-    rc = L.ifl_inverse_f32(None, None, None, 2, 4, 5, 5, 3, 3, 7, 0, None, 0, None, None)
+    rc = L.ifl_inverse_f32(None, None, None, 2, 4, 5, 5, 3, 3, 7, 0, None, 0, None, None, None)
     assert rc == -1 and b"unknown order" in L.ifl_last_error()
     # empty batch is a no-op success and clears the error
-    assert L.ifl_inverse_f32(None, None, None, 0, 4, 5, 5, 3, 3, 0, 0, None, 0, None, None) == 0
+    assert L.ifl_inverse_f32(None, None, None, 0, 4, 5, 5, 3, 3, 0, 0, None, 0, None, None, None) == 0
     assert L.ifl_last_error() == b""
     assert L.ifl_forward_f32(None, None, None, None, 0, 4, 5, 5, 3, 3, 0, 0, None, 0, None) == 0
     # null tensors with a non-empty batch
-    rc = L.ifl_inverse_f32(None, None, None, 1, 4, 5, 5, 3, 3, 0, 0, None, 0, None, None)
+    rc = L.ifl_inverse_f32(None, None, None, 1, 4, 5, 5, 3, 3, 0, 0, None, 0, None, None, None)
     assert rc == -1 and b"null tensor" in L.ifl_last_error()
     rc = L.ifl_conv2d_f32(None, None, None, None, 1, 4, 4, 2, 2, 3, 3, 0, 0, None, 0, None)
     assert rc == -1 and b"kernel larger" in L.ifl_last_error()

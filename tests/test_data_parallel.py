@@ -73,3 +73,26 @@ def test_two_rank_gloo_allreduce(tmp_path):
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-3000:]
     assert r.stdout.count("ok") == 2
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` run plainly starts two ranks by itself (before anything touches a GPU) and rank 0's line
+    says n_gpus 2; strong scaling shards the batch of 128; a process group of the wrong size is refused.  --dry: the same
+    control flow on CPU tensors over gloo, no kernel."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(OMP_NUM_THREADS="1")
+    bench = os.path.join(ROOT, "bench.py")
+    for scaling, per_rank in (("weak", 128), ("strong", 64)):
+        r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry", "--backend", "gloo",
+                            "--scaling", scaling, "--master-port", "29537"], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["per_rank_batch"] == per_rank
+        assert abs(line["dw_mean"] - 1.5) < 1e-6  # mean of the ranks' values 1 and 2: the collective ran
+    # one process that claims to be a 1-rank group must not pass for --gpus 2
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0", "--dry", "--backend", "gloo"],
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "process group has 1 ranks" in (r.stdout + r.stderr)

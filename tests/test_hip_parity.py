@@ -326,20 +326,13 @@ def test_empty_batch_and_errors(H):
                   flags=H.FLAG_NO_MFMA)
 
 
-def _no_split(on):
-    """the library reads IFL_NO_SPLIT at every scan launch (scan_mfma.hip, launch_one)"""
-    if on:
-        os.environ["IFL_NO_SPLIT"] = "1"
-    else:
-        os.environ.pop("IFL_NO_SPLIT", None)
-
-
-@pytest.mark.parametrize("shape", [(128, 64, 32, 32, 3), (128, 32, 32, 16, 3), (40, 64, 24, 32, 2), (13, 48, 32, 32, 3),
-                                   (5, 64, 17, 4, 3), (9, 20, 20, 8, 2), (3, 32, 31, 12, 3)],
+@pytest.mark.parametrize("shape", [(128, 64, 32, 32, 3), (128, 32, 32, 32, 3), (40, 64, 24, 32, 2), (13, 32, 17, 32, 2),
+                                   (128, 32, 32, 16, 3), (13, 48, 32, 32, 3), (5, 64, 17, 4, 3), (3, 32, 31, 12, 3)],
                          ids=lambda s: "B%d_C%d_%dx%d_K%d" % s)
 def test_split_scan_equals_whole_image_scan(H, shape):
-    """Two workgroups per image (k_scan_split: mailbox hand-off of rows 14, 15) against one workgroup per image, at the
-    bench's full size and on ragged ones (H not a multiple of 16, padded channels, a batch that is not a multiple of 8).
+    """Two workgroups per image (the duo scan: mailbox hand-off of rows 14, 15; the shapes with 32 or 64 channels on
+    32-pixel rows) against one workgroup per image (IFL_FLAG_WHOLE_IMAGE), at the bench's full size and on ragged ones (H
+    not a multiple of 16, a batch that is not a multiple of 8; the other shapes run the same kernel either way).
     The arithmetic per tile is the same instruction sequence on the same operands, so the results are bit-identical --
     on every one of many back-to-back launches (tags are per-image launch generations: a stale granule of an earlier
     launch must never be taken for a fresh one), for all four orders, forward and adjoint."""
@@ -350,12 +343,8 @@ def test_split_scan_equals_whole_image_scan(H, shape):
     w = w.cuda()
     x = torch.randn(B, C, Hh, Ww, generator=gen).cuda()
     for order in ("TL", "TR", "BL", "BR"):
-        _no_split(True)
-        try:
-            z_ref = H.inverse(x, w, order)
-            dx_ref, dw_ref, _ = H.backward(x, z_ref, w, order)
-        finally:
-            _no_split(False)
+        z_ref = H.inverse(x, w, order, H.FLAG_WHOLE_IMAGE)
+        dx_ref, dw_ref, _ = H.backward(x, z_ref, w, order, H.FLAG_WHOLE_IMAGE)
         for it in range(12 if order == "TL" else 2):
             z = H.inverse(x, w, order)
             assert torch.equal(z, z_ref), (order, it)
@@ -379,11 +368,7 @@ def test_split_scan_redoes_void_images_whole(H, oracle):
     z = H.inverse(dev(x), dev(w))
     for b in range(B):
         assert rel_err(host(z)[b], z_o[b]) < TOL, b
-    _no_split(True)
-    try:
-        z_w = H.inverse(dev(x), dev(w))
-    finally:
-        _no_split(False)
+    z_w = H.inverse(dev(x), dev(w), "TL", H.FLAG_WHOLE_IMAGE)
     for b in range(B):
         assert rel_err(host(z_w)[b], z_o[b]) < TOL, b
 
@@ -398,11 +383,7 @@ def test_split_scan_streams_and_graph_replay(H):
     w[:, -1, -1, -1] = 1.0
     w = w.cuda()
     xs = [torch.randn(B, C, Hh, Ww, device="cuda") for _ in range(2)]
-    _no_split(True)
-    try:
-        refs = [H.inverse(x, w) for x in xs]
-    finally:
-        _no_split(False)
+    refs = [H.inverse(x, w, "TL", H.FLAG_WHOLE_IMAGE) for x in xs]
     torch.cuda.synchronize()
     # two side streams, interleaved launches
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
@@ -434,26 +415,39 @@ def test_split_scan_streams_and_graph_replay(H):
 
 
 def test_scan_state_is_caller_owned(H):
-    """The split scan runs only on a block the caller registered (ifl_scan_state_register: the library never allocates);
-    without one the whole-image kernel computes the same bits; a block that is too small is refused."""
+    """The two-workgroup scan runs only on a block the caller passes (scan_state: the library never allocates and keeps no
+    registry); without one, or with IFL_FLAG_WHOLE_IMAGE, one workgroup per image computes the same bits; a block that is
+    not 256-byte aligned is refused; z aliasing x is refused."""
     torch.manual_seed(9)
     B, C, Hh, Ww, K = 8, 64, 32, 32, 3
     w = torch.nn.init.dirac_(torch.empty(C, C, K, K)) + 0.02 * torch.randn(C, C, K, K)
     w[:, -1, -1, -1] = 1.0
     w = w.cuda()
     x = torch.randn(B, C, Hh, Ww, device="cuda")
-    z_split = H.inverse(x, w)  # (the host layer registered this stream's block on its first scan)
+    z_split = H.inverse(x, w)  # (the host layer passes this stream's block)
     L = H.lib()
     stream = torch.cuda.current_stream().cuda_stream
-    key = (torch.cuda.current_device(), stream)
-    assert key in H._scan_states
-    assert L.ifl_scan_state_register(None, 0, stream) == 0  # forget it: whole-image kernel from now on
-    try:
-        z_whole = H.inverse(x, w)
-        small = torch.zeros(4096, dtype=torch.uint8, device="cuda")
-        assert L.ifl_scan_state_register(small.data_ptr(), small.numel(), stream) == -3  # IFL_EWORKSPACE
-        assert b"bytes needed" in L.ifl_last_error()
-    finally:
-        st = H._scan_states[key]
-        assert L.ifl_scan_state_register(st.data_ptr(), st.numel(), stream) == 0
-    assert torch.equal(z_split, z_whole) and torch.equal(H.inverse(x, w), z_split)
+    assert (torch.cuda.current_device(), stream) in H._scan_states
+    nb = L.ifl_workspace_bytes(H.OP_INVERSE, B, C, Hh, Ww, K, K, 0)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    z_none = torch.empty_like(x)
+    assert L.ifl_inverse_f32(x.data_ptr(), w.data_ptr(), z_none.data_ptr(), B, C, Hh, Ww, K, K, 0, 0, ws.data_ptr(), nb, None,
+                             None, stream) == 0
+    z_whole = H.inverse(x, w, "TL", H.FLAG_WHOLE_IMAGE)
+    assert torch.equal(z_split, z_none) and torch.equal(z_split, z_whole)
+    own = torch.zeros(L.ifl_scan_state_bytes() + 256, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    off = (-own.data_ptr()) % 256
+    z_own = torch.empty_like(x)
+    for _ in range(3):
+        assert L.ifl_inverse_f32(x.data_ptr(), w.data_ptr(), z_own.data_ptr(), B, C, Hh, Ww, K, K, 0, 0, ws.data_ptr(), nb, None,
+                                 own.data_ptr() + off, stream) == 0
+        assert torch.equal(z_own, z_split)
+    assert L.ifl_inverse_f32(x.data_ptr(), w.data_ptr(), z_own.data_ptr(), B, C, Hh, Ww, K, K, 0, 0, ws.data_ptr(), nb, None,
+                             own.data_ptr() + off + 16, stream) == -1  # IFL_EINVAL
+    assert b"256-byte aligned" in L.ifl_last_error()
+    assert L.ifl_inverse_f32(x.data_ptr(), w.data_ptr(), x.data_ptr(), B, C, Hh, Ww, K, K, 0, 0, ws.data_ptr(), nb, None, None,
+                             stream) == -1
+    assert b"must not alias" in L.ifl_last_error()
+    with pytest.raises(RuntimeError, match="must not alias"):
+        H.inverse(x, w, out=x)

@@ -8,9 +8,7 @@ import invflow_hip as H
 from bench import ref_init_weight, B, C, HH, WW
 w = ref_init_weight(torch.Generator().manual_seed(0)).cuda()
 x = torch.randn(B, C, HH, WW, device="cuda")
-os.environ["IFL_NO_SPLIT"] = "1"
-ref = H.inverse(x, w)
-del os.environ["IFL_NO_SPLIT"]
+ref = H.inverse(x, w, "TL", H.FLAG_WHOLE_IMAGE)
 z = torch.empty_like(x)
 N, CH = int(sys.argv[1]) if len(sys.argv) > 1 else 20000, 100
 times = []

@@ -109,6 +109,27 @@ static int run_conv(const float *in, const float *w, const float *bias, float *o
     return launch_conv_direct(in, w, bias, out, B, Ci, Co, H, W, OH, OW, KH, KW, pt, pl, s);
 }
 
+// xhat = A z with the layer's effective weight (and log|det A| per image when `logdet`): two launches where the MFMA
+// convolution applies (effective weight + fp16 pack + log-det in one, then the convolution), the direct kernels otherwise
+static int run_conv_eff(const float *z, const float *w, float *weff, float *xhat, float *logdet, const Geom &g, unsigned flags,
+                        void *pack, hipStream_t s)
+{
+    int rc;
+    const int pt = g.flipH ? 0 : g.KH - 1, pl = g.flipW ? 0 : g.KW - 1; // padding corner; also the diagonal tap's stored position
+    if (pack && !(flags & (IFL_FLAG_NO_MFMA | IFL_FLAG_EXACT_F32)) && conv_mfma_supported(g.C, g.C, g.H, g.W, g.H, g.W, g.KH, g.KW, pt, pl)) {
+        const ConvEff eff{weff, logdet, pt, pl, g.general_diag, g.B, g.H, g.W};
+        ProfScope ps(IFL_PROF_CONV, s);
+        return launch_conv_mfma(z, w, nullptr, xhat, pack, g.B, g.C, g.H, g.W, g.KH, g.KW, pt, pl, s, &eff);
+    }
+    if ((rc = launch_effw(w, weff, g, s))) return rc;
+    {
+        ProfScope ps(IFL_PROF_CONV, s);
+        if ((rc = launch_conv_direct(z, weff, nullptr, xhat, g.B, g.C, g.C, g.H, g.W, g.H, g.W, g.KH, g.KW, pt, pl, s))) return rc;
+    }
+    if (logdet && (rc = launch_logdet(w, logdet, g, s))) return rc;
+    return IFL_OK;
+}
+
 // Forward -> backward side channel ("carry", caller-owned, ifl_carry_bytes): the folded + packed weights of
 // the adjoint, produced by the forward call's single fold launch, and two words collecting max|z| / max|dx|
 // from the scans (the weight-gradient kernel's power-of-two prescale), so that the backward needs neither
@@ -308,17 +329,7 @@ int ifl_forward_f32(const float *z, const float *w, float *xhat, float *logdet, 
     float *weff = cv.take<float>((size_t)KH * KW * C * C);
     void *pack = cv.take<unsigned char>(conv_pack_bytes(C, C, KH, KW));
     if (!cv.ok()) IFL_FAIL(IFL_EWORKSPACE, "ifl_forward_f32: workspace too small: need %zu bytes, have %zu", cv.off, cv.cap);
-    if ((rc = launch_effw(w, weff, g, s))) return rc;
-    int pt, pl, dkh, dkw;
-    order_pads(g, pt, pl, dkh, dkw);
-    {
-        ProfScope ps(IFL_PROF_CONV, s);
-        if ((rc = run_conv(z, weff, nullptr, xhat, B, C, C, H, W, H, W, KH, KW, pt, pl,
-                           (flags & (IFL_FLAG_NO_MFMA | IFL_FLAG_EXACT_F32)) ? nullptr : pack, s)))
-            return rc;
-    }
-    if (logdet && (rc = launch_logdet(w, logdet, g, s))) return rc;
-    return IFL_OK;
+    return run_conv_eff(z, w, weff, xhat, logdet, g, flags, pack, s);
 }
 
 static int dw_impl(const float *z, const float *dx, float *dw, int B, int C, int H, int W, int KH, int KW, int order,
@@ -394,12 +405,7 @@ int ifl_backward_f32(const float *gout, const float *z, const float *x, const fl
         float *mix = cv.take<float>(n);
         if (!cv.ok())
             IFL_FAIL(IFL_EWORKSPACE, "ifl_backward_f32: workspace too small: need %zu bytes, have %zu", cv.off, cv.cap);
-        int pt, pl, dkh, dkw;
-        order_pads(g, pt, pl, dkh, dkw);
-        if ((rc = launch_effw(w, weff, g, s))) return rc;
-        if ((rc = run_conv(z, weff, nullptr, az, B, C, C, H, W, H, W, KH, KW, pt, pl,
-                           (flags & (IFL_FLAG_NO_MFMA | IFL_FLAG_EXACT_F32)) ? nullptr : pack, s)))
-            return rc;
+        if ((rc = run_conv_eff(z, w, weff, az, nullptr, g, flags, pack, s))) return rc;
         // d/dW of rw*mean_b||x - A z||^2 = -(2 rw / B) sum r (x) shifted z  -> fold into the dW reduction
         if ((rc = launch_recon_mix(u, x, az, mix, 2.0f * recon_weight / (float)B, recon_loss, 1.0f / (float)B, n, s)))
             return rc;

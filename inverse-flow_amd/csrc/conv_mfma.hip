@@ -53,22 +53,51 @@ template <int C, int KH, int KW, int WT> struct ConvCfg {
     static_assert(4 * PB + (KH * PC + KW) * 16 < 65536, "fragment offsets must fit the ds offset field");
 };
 
-// apack[wv][t][q][hl][lane][8] (fp16): lane = m + 16 gk holds row co = 16 wv + m, k = ci = 32 q + 8 gk + j of tap t
+// apack[wv][t][q][hl][lane][8] (fp16): lane = m + 16 gk holds row co = 16 wv + m, k = ci = 32 q + 8 gk + j of tap t.
+// With eff.weff != nullptr the launch is the whole preparation of the layer's reverse pass (ifl_forward_f32) in one:
+// the effective weight What (diagonal tap forced unit-lower-triangular, or lower-triangular with its own diagonal:
+// inf/utils/solve_mc.py:105-109, inf/layers/emerging/inverse_op_cython.pyx:64) is what gets packed, its fp32 copy goes to
+// eff.weff (the kernel's fp32 redo of a band reads it), and workgroup 0 writes log|det A| per image
+// (inf/layers/emerging/emerging_module.py:26-32; 0 for the unit diagonal) -- the reference's reverse is
+// inv_conv_fwd_cuda_inverse, inv_conv_with_bp_kernel_general.cu:203-264.
 __global__ __launch_bounds__(256) void k_convpack(const float *__restrict__ w, _Float16 *__restrict__ apack, int C, int KH,
-                                                  int KW)
+                                                  int KW, ConvEff eff)
 {
     const int NT = KH * KW, NQ = C / 32;
+    const int tdiag = eff.dkh * KW + eff.dkw;
     const size_t total = (size_t)(C / 16) * NT * NQ * 64 * 8;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int j = (int)(i % 8), lane = (int)((i / 8) % 64);
         const int q = (int)((i / 512) % NQ), t = (int)((i / (512 * (size_t)NQ)) % NT), wv = (int)(i / (512 * (size_t)NQ * NT));
         const int co = 16 * wv + (lane & 15), ci = 32 * q + 8 * (lane >> 4) + j;
-        const float v = w[((size_t)co * C + ci) * NT + t];
+        float v = w[((size_t)co * C + ci) * NT + t];
+        if (eff.weff) {
+            if (t == tdiag) {
+                if (ci > co) v = 0.f;
+                else if (ci == co && !eff.general_diag) v = 1.f;
+            }
+            eff.weff[((size_t)co * C + ci) * NT + t] = v;
+        }
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)((v - (float)hi) * LO_SCALE);
         const size_t base = ((((size_t)wv * NT + t) * NQ + q) * 2) * 64 * 8;
         apack[base + (size_t)lane * 8 + j] = hi;
         apack[base + (size_t)64 * 8 + (size_t)lane * 8 + j] = lo;
+    }
+    if (eff.logdet && blockIdx.x == 0) {
+        // fixed-order tree reduction over channels -> deterministic
+        __shared__ double red[256];
+        double sum = 0.0;
+        if (eff.general_diag)
+            for (int c = threadIdx.x; c < C; c += 256) sum += log(fabs((double)w[((size_t)c * C + c) * NT + tdiag]));
+        red[threadIdx.x] = sum;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        const float v = (float)(red[0] * (double)eff.H * (double)eff.W);
+        for (int b = threadIdx.x; b < eff.B; b += 256) eff.logdet[b] = v;
     }
 }
 
@@ -388,12 +417,15 @@ static int launch_conv_one(const float *in, const void *apack, const float *w, c
 
 // apack: conv_mfma_pack_bytes of workspace; w: (C, C, KH, KW) fp32 (also read by the fp32 redo of a band)
 int launch_conv_mfma(const float *in, const float *w, const float *bias, float *out, void *apack, int B, int C, int H,
-                     int W, int KH, int KW, int pt, int pl, hipStream_t s)
+                     int W, int KH, int KW, int pt, int pl, hipStream_t s, const ConvEff *eff)
 {
     if (B == 0) return IFL_OK;
     const size_t total = (size_t)KH * KW * C * C * 2;
-    hipLaunchKernelGGL(k_convpack, dim3((unsigned)((total / 2 + 255) / 256)), dim3(256), 0, s, w, (_Float16 *)apack, C, KH, KW);
+    ConvEff e{nullptr, nullptr, 0, 0, 0, B, H, W};
+    if (eff) e = *eff;
+    hipLaunchKernelGGL(k_convpack, dim3((unsigned)((total / 2 + 255) / 256)), dim3(256), 0, s, w, (_Float16 *)apack, C, KH, KW, e);
     IFL_HIP(hipGetLastError());
+    if (e.weff) w = e.weff; // (the fp32 redo of a band multiplies the effective weight)
 #define IFL_CASE(CC, KK, WW) \
     if (C == CC && KH == KK && W == WW) return launch_conv_one<CC, KK, KK, WW>(in, apack, w, bias, out, B, H, pt, pl, s);
     IFL_CASE(64, 3, 32)

@@ -142,9 +142,17 @@ int launch_wgrad_mfma(const float *gz, const float *x, float *dw, void *ws, int 
 // ---- MFMA dense same-size convolution (conv_mfma.hip): Ci = Co in {32,64}, K in {2x2,3x3}, W in {16,32} --------
 bool conv_mfma_supported(int Ci, int Co, int H, int W, int OH, int OW, int KH, int KW, int pt, int pl);
 size_t conv_mfma_pack_bytes(int C, int KH, int KW);
-// apack: conv_mfma_pack_bytes of workspace (packed by the launch); w: (C, C, KH, KW) fp32
+// apack: conv_mfma_pack_bytes of workspace (packed by the launch); w: (C, C, KH, KW) fp32.
+// eff (optional): the layer's reverse pass -- the packing launch applies the mask of the diagonal tap at stored position
+// (dkh, dkw), leaves the effective weight in eff->weff (C*C*KH*KW floats) and log|det A| per image in eff->logdet (or NULL)
+struct ConvEff {
+    float *weff;
+    float *logdet;
+    int dkh, dkw, general_diag;
+    int B, H, W;
+};
 int launch_conv_mfma(const float *in, const float *w, const float *bias, float *out, void *apack, int B, int C, int H,
-                     int W, int KH, int KW, int pt, int pl, hipStream_t s);
+                     int W, int KH, int KW, int pt, int pl, hipStream_t s, const ConvEff *eff = nullptr);
 
 // ---- small layers (small_layers.hip): C <= 8, image + result resident in LDS ------------------------------------
 bool scan_resident_supported(const Geom &g);

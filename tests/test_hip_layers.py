@@ -82,6 +82,39 @@ def test_layer_autograd_matches_oracle(H, oracle, order, shape):
         assert rel_err(host(z2), z_o) < TOL and rel_err(host(dx2), u_o) < TOL and rel_err(host(dw2), dw_o) < 3 * TOL
 
 
+# BASELINE.json configs as (batch, C, H, W, K) of their inverse-flow layers: if_glow_mnist (configs[2]: batch 100, 2x2 kernels
+# after the squeezes, inf/experiments/if_glow_mnist.py:156-159,190), if_glow_cifar per GPU of 8 (configs[3]: 256/8 = 32,
+# C = 12/24/48, inf/experiments/if_glow_cifar.py:48-50,94-96), if_multiGPU_imagenet32 (configs[4]: C = 256)
+CONFIG_LAYERS = [(100, 4, 14, 14, 2), (100, 8, 7, 7, 2), (32, 12, 16, 16, 3), (32, 24, 8, 8, 3), (32, 48, 4, 4, 3), (16, 256, 8, 8, 3)]
+
+
+@pytest.mark.parametrize("shape", CONFIG_LAYERS, ids=lambda s: "b%dc%d_%dx%d_k%d" % s)
+def test_config_layer_shapes_through_flowsequential(H, oracle, shape):
+    """The layers of BASELINE.json's model configs at the configs' own batch sizes, through the layer's autograd and a
+    FlowSequential (log-det counted once, log p = base log-prob), against the fp64 oracle."""
+    from inf.layers.flowsequential import FlowSequential
+    from inf.layers.inv_conv import inv_flow_no_pad
+    from inf.train.losses import NegativeGaussianLoss
+    B, C, Hh, Ww, K = shape
+    torch.manual_seed(B + C)
+    layer = inv_flow_no_pad(C, C, (K, K)).cuda()
+    model = FlowSequential(NegativeGaussianLoss((C, Hh, Ww)), layer).cuda()
+    x = torch.randn(B, C, Hh, Ww, device="cuda", requires_grad=True)
+    z, logp = model(x)
+    assert torch.allclose(logp, model.base_distribution.log_prob(z))
+    (-logp.mean()).backward()
+    w64, x64 = host(layer.weight_fwd), host(x)
+    z_o = oracle.inverse(x64, w64, 0, "TL", nthreads=8)
+    assert rel_err(host(z), z_o) < TOL
+    # d(-mean log p)/dz = z / B for the standard normal base
+    g_o = z_o / B
+    u_o = oracle.dy(g_o, w64, 0, "TL", nthreads=8)
+    dw_o = oracle.dw(z_o, u_o, (K, K), 0, "TL", nthreads=8)
+    assert rel_err(host(x.grad), u_o) < TOL
+    assert rel_err(host(layer.weight_fwd.grad), dw_o) < 3 * TOL
+    assert rel_err(host(model.reconstruct(x.detach())), x64) < 1e-4
+
+
 def test_inv_flow_unit_and_sequential(H):
     from inf.layers.flowsequential import FlowSequential
     from inf.layers.inv_conv import inv_flow_no_pad

@@ -14,6 +14,7 @@ from conftest import golden_files, load_golden, rel_err
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
+ORDERS = ["TL", "TR", "BL", "BR"]
 INV = golden_files("inv_")
 
 
@@ -236,6 +237,32 @@ def test_recon_term(H, oracle):
     assert rel_err(host(dw), dw_o) < TOL
     assert rel_err(host(dx), u) < TOL
     assert abs(float(rl) - (r ** 2).sum() / B) < 1e-4 * (r ** 2).sum() / B
+
+
+@pytest.mark.parametrize("order", ["TL", "TR", "BL", "BR"])
+@pytest.mark.parametrize("shape", [(4, 64, 32, 32, 3), (2, 32, 16, 16, 2)], ids=lambda s: "b%dc%d_%dx%d_k%d" % s)
+def test_recon_term_mfma_route(H, oracle, shape, order):
+    """The recon term on the MFMA route (x^ = A z by k_conv_mfma with the effective weight packed in the same launch, the
+    mixed gradient through k_wgrad_mfma without carried maxima), every order, against the oracle's closed form."""
+    B, C, Hh, Ww, K = shape
+    rng = np.random.default_rng(40 + C + ORDERS.index(order))
+    x = rng.standard_normal((B, C, Hh, Ww)).astype(np.float32)
+    g = rng.standard_normal((B, C, Hh, Ww)).astype(np.float32)
+    w = _weights(rng, C, K, K, "refinit", order, oracle).astype(np.float32)
+    w64 = w.astype(np.float64)
+    z = (oracle.inverse(x.astype(np.float64), w64, 0, order, nthreads=8) + 0.01 * rng.standard_normal((B, C, Hh, Ww))).astype(np.float32)
+    rw = 0.35
+    dx, dw, rl = H.backward(dev(g), dev(z), dev(w), order, 0, x=dev(x), recon_weight=rw)
+    z64 = z.astype(np.float64)
+    u = oracle.dy(g.astype(np.float64), w64, 0, order, nthreads=8)
+    r = x.astype(np.float64) - oracle.forward(z64, w64, 0, order, nthreads=8)
+    dw_o = oracle.dw(z64, u + (2 * rw / B) * r, (K, K), 0, order, nthreads=8)
+    assert rel_err(host(dx), u) < TOL
+    assert rel_err(host(dw), dw_o) < TOL
+    assert abs(float(rl) - (r ** 2).sum() / B) < 1e-4 * (r ** 2).sum() / B
+    # and the reverse pass with its log-det, which shares the packing launch
+    xh, ld = H.forward(dev(z), dev(w), order, 0, want_logdet=True)
+    assert rel_err(host(xh), oracle.forward(z64, w64, 0, order, nthreads=8)) < TOL and float(ld.abs().max()) == 0.0
 
 
 # ---------------------------------------------------------------------------------------------

@@ -2,7 +2,7 @@
 # Round profile on the GPU box: bench line, rocprofv3 kernel stats, and the two HBM counter passes
 # (separate --pmc runs, as MI355X_MICROARCH.md prescribes).  Outputs under gpurun_out/prof_<tag>/.
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT

@@ -39,6 +39,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the configs[2] training-step figure")
     ap.add_argument("--flags", type=int, default=0, help="IFL_FLAG_* bits passed to the library")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with hipEvents")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL)")
@@ -157,6 +158,31 @@ def accuracy(H, w, x, g, flags, nimg=3):
     return {"rel_err_z": rel(z, z_o), "rel_err_dx": rel(dx, u_o), "rel_err_dw": rel(dw, dw_o),
             "logdet_abs_err": float(ld.abs().max().item()), "images": nimg,
             "reference": "oracle/ (fp64 restatement of inf/utils/solve_mc.py:88-114 and the adjoint / outer-product forms)"}
+
+
+def train_step_figure(dev, steps=20, warmup=5):
+    """BASELINE configs[2]: if_glow_mnist (L = 2, K = 16; inf/experiments/if_glow_mnist.py:33-190) full FlowSequential training
+    step -- loss, backward, clip, Adam -- under bf16 autocast on synthetic uniform-dequantised 28x28x1 images, batch 100:
+    ms per step and bits/dim (random-init weights: the bits/dim is that of an untrained model).  Not part of `value`."""
+    import torch
+    from inf.experiments.if_glow_mnist import DEFAULT_CONFIG as cfg, create_model
+    from inf.train.step import TrainStep, bits_per_dim
+    torch.manual_seed(3)
+    model = create_model(num_blocks=cfg["num_blocks"], block_size=cfg["block_size"], coupling_width=cfg["coupling_width"],
+                         n_bins=cfg["n_bins"], tail_bound=cfg["tail_bound"]).to(dev)
+    step = TrainStep(model, torch.optim.Adam(model.parameters(), lr=cfg["lr"]), grad_clip_norm=1.0, autocast=True)
+    x = torch.randint(0, 256, (cfg["batch_size"], 1, 28, 28), device=dev).float()
+    for _ in range(warmup):
+        loss = step(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step(x)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"config": "configs[2]: if_glow_mnist L=2, K=16, batch 100, 28x28x1, bf16 autocast, Adam, synthetic uniform-dequantised data",
+            "ms_per_step": ms, "images_per_s": cfg["batch_size"] / (ms * 1e-3), "bits_per_dim": bits_per_dim(float(loss), 28 * 28),
+            "parameters": sum(p.numel() for p in model.parameters()), "steps": steps}
 
 
 def committed_counters(kernel_us, world):
@@ -328,6 +354,8 @@ def main():
             "forward_logdet": {"ms": fwd_ms, "images_per_s": nb / (fwd_ms * 1e-3),
                                "what": "ifl_forward_f32: z -> x^ = A z and log|det A| (the layer's reverse), per rank, not part of value"},
         }
+        if world == 1 and not args.no_train_step:
+            out["train_step"] = train_step_figure(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w_host)
         print(json.dumps(out), flush=True)

@@ -101,8 +101,9 @@ class SmoothLeakyRelu(FlowActivationLayer):
 
 
 def spline_tables(unnormalized_widths, unnormalized_heights, unnormalized_derivatives, tail_bound):
-    """Knot tables of the shared-weight spline with linear tails: cumwidths, cumheights, derivatives (n_bins + 1 entries
-    each), by the formulas of splines/rational_quadratic.py:35-46,97-116 applied to the 1-D parameters."""
+    """Knot tables of the spline with linear tails: cumwidths, cumheights, derivatives (n_bins + 1 entries along the last
+    axis), by the formulas of splines/rational_quadratic.py:35-46,97-116.  1-D parameters (shared weights) or one set per
+    element (individual weights: leading axes (1, C, H, W))."""
     nb = unnormalized_widths.shape[-1]
     constant = float(np.log(np.exp(1 - MIN_DERIVATIVE) - 1))
     ud = F.pad(unnormalized_derivatives, pad=(1, 1)) + constant
@@ -116,9 +117,9 @@ def spline_tables(unnormalized_widths, unnormalized_heights, unnormalized_deriva
         cum = F.pad(cum, pad=(1, 0), mode='constant', value=0.0)
         cum = (hi - lo) * cum + lo
         edge = torch.zeros_like(cum)
-        edge[0], edge[-1] = lo, hi
+        edge[..., 0], edge[..., -1] = lo, hi
         keep = torch.ones_like(cum)
-        keep[0] = keep[-1] = 0.0
+        keep[..., 0] = keep[..., -1] = 0.0
         return cum * keep + edge  # cum[0] = lo, cum[-1] = hi without an in-place write (same values, same gradients)
 
     cw = knots(unnormalized_widths, left, right, MIN_BIN_WIDTH)
@@ -213,18 +214,28 @@ class SplineActivation(FlowActivationLayer):
 
 
 def _spline_torch(layer, input, inverse):
-    """The spline on torch expressions (reference semantics, shared or individual weights): per-element tables."""
-    if layer.individual_weights:
-        uw, uh, ud = layer.unnormalized_widths, layer.unnormalized_heights, layer.unnormalized_derivatives
-        raise NotImplementedError("individual spline weights are outside the HIP path; use the reference layer")
-    cw, ch, dv = layer._tables()
+    """The spline on torch expressions (reference semantics, activations.py:126-217 over
+    splines/rational_quadratic.py:68-175): shared weights, or one set of knots per element (individual_weights: the
+    MNIST Glow's activation -- per-element tables, gathered along the bin axis)."""
     tb = float(layer.tail_bound)
     inside = (input >= -tb) & (input <= tb)
-    knots = ch if inverse else cw
-    edges = knots.clone()
-    edges[-1] = edges[-1] + 1e-6
-    k = (torch.sum(input[..., None] >= edges, dim=-1) - 1).clamp(0, layer.n_bins - 1)
-    a, b, c, e, d0, d1 = cw[k], cw[k + 1], ch[k], ch[k + 1], dv[k], dv[k + 1]
+    orig = input
+    input = torch.where(inside, input, torch.zeros_like(input))  # (the tails are the identity: keep their lanes finite)
+    if layer.individual_weights:
+        cw, ch, dv = spline_tables(layer.unnormalized_widths, layer.unnormalized_heights, layer.unnormalized_derivatives, tb)
+        cw, ch, dv = (t.expand(input.shape[0], *t.shape[1:]) for t in (cw, ch, dv))
+        knots = ch if inverse else cw
+        edges = torch.cat([knots[..., :-1], knots[..., -1:] + 1e-6], dim=-1)
+        k = (torch.sum(input[..., None] >= edges, dim=-1) - 1).clamp(0, layer.n_bins - 1)[..., None]
+        pick = lambda t, o: torch.gather(t, -1, k + o)[..., 0]  # noqa: E731
+        a, b, c, e, d0, d1 = pick(cw, 0), pick(cw, 1), pick(ch, 0), pick(ch, 1), pick(dv, 0), pick(dv, 1)
+    else:
+        cw, ch, dv = layer._tables()
+        knots = ch if inverse else cw
+        edges = knots.clone()
+        edges[-1] = edges[-1] + 1e-6
+        k = (torch.sum(input[..., None] >= edges, dim=-1) - 1).clamp(0, layer.n_bins - 1)
+        a, b, c, e, d0, d1 = cw[k], cw[k + 1], ch[k], ch[k + 1], dv[k], dv[k + 1]
     w, h = b - a, e - c
     delta = h / w
     if inverse:
@@ -247,7 +258,7 @@ def _spline_torch(layer, input, inverse):
         out = c + num / den
         dnum = delta.pow(2) * (d1 * theta.pow(2) + 2 * delta * t1 + d0 * (1 - theta).pow(2))
         lad = torch.log(dnum) - 2 * torch.log(den)
-    out = torch.where(inside, out, input)
+    out = torch.where(inside, out, orig)
     lad = torch.where(inside, lad, torch.zeros_like(lad))
     return out, lad.flatten(start_dim=1).sum(dim=-1)
 

@@ -1,0 +1,91 @@
+"""GPU: the train-step replacement (inf/train/step.py: get_loss, backward, clip, gradient bucket, optimizer step --
+inf/train/experiment.py:160-195,272-311) on the MNIST-Glow-shaped model built from this package's layers
+(inf/experiments/if_glow_mnist.py), against a CPU fp64 run of the same model built from the reference's own layers
+(tests/golden/make_golden_trainstep.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fixture():
+    d = np.load(os.path.join(GOLDEN, "trainstep_glow_b6_8x8_L2K2.npz"))
+    return {k: d[k] for k in d.files}
+
+
+def build(fixture, dtype=torch.float32):
+    from inf.experiments.if_glow_mnist import create_model
+    B, c, h, w, width, nb, tb = (int(v) for v in fixture["config"])
+    model = create_model(dequantize=False, image_size=(c, h, w), num_blocks=2, block_size=2, coupling_width=width,
+                         split_width=width, n_bins=nb, tail_bound=tb, inv_conv_no_pad=True).cuda()
+    sd = {k[3:]: torch.from_numpy(v).to(dtype) for k, v in fixture.items() if k.startswith("sd/")}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected  # the reference-layer model's state_dict loads as is
+    assert all("mask" in k or "_device_probe" in k for k in missing), missing
+    return model
+
+
+def test_loss_and_every_gradient_match_reference_layers(fixture):
+    from inf.train.step import get_loss
+    model = build(fixture)
+    x = torch.from_numpy(fixture["x"]).float().cuda()
+    loss = get_loss(model, x)
+    loss.backward()
+    assert abs(float(loss) - float(fixture["loss"])) < 2e-5 * abs(float(fixture["loss"]))
+    grads = {k[5:]: v for k, v in fixture.items() if k.startswith("grad/")}
+    params = dict(model.named_parameters())
+    assert set(grads) == set(params)
+    worst = 0.0
+    for name, g_ref in grads.items():
+        g = params[name].grad
+        assert g is not None, name
+        if np.linalg.norm(g_ref) == 0:
+            assert float(g.abs().max()) < 1e-6, name
+            continue
+        e = rel_err(g.detach().cpu().double().numpy(), g_ref)
+        worst = max(worst, e)
+        assert e < 5e-4, (name, e)  # fp32 through 20 layers against fp64
+    assert worst > 0
+
+
+def test_train_step_runs_and_learns(fixture):
+    from inf.train.step import TrainStep, bits_per_dim
+    torch.manual_seed(0)
+    model = build(fixture)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    step = TrainStep(model, opt, grad_clip_norm=1.0, clear_grads=True)
+    x = torch.from_numpy(fixture["x"]).float().cuda()
+    # every gradient is a view of the one flat bucket the data-parallel all-reduce works on
+    assert all(p.grad.data_ptr() >= step.bucket.flat.data_ptr() for p in model.parameters())
+    losses = [float(step(x)) for _ in range(25)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0] - 1.0
+    assert abs(losses[0] - float(fixture["loss"])) < 2e-5 * abs(float(fixture["loss"]))
+    assert bits_per_dim(losses[0], x[0].numel()) > 0
+    # bf16 autocast around the model (BASELINE configs[2]): the library layers compute in fp32, the conditioners in bf16
+    model2 = build(fixture)
+    step2 = TrainStep(model2, torch.optim.Adam(model2.parameters(), lr=1e-3), autocast=True)
+    l2 = float(step2(x))
+    assert abs(l2 - float(fixture["loss"])) < 2e-2 * abs(float(fixture["loss"]))
+
+
+def test_config3_model_builds_at_its_own_size():
+    """if_glow_mnist as configured (L = 2, K = 16, batch 100, 28x28x1, 2x2 inverse-flow layers, per-element splines,
+    coupling width 512): one training step on synthetic dequantised data."""
+    from inf.experiments.if_glow_mnist import DEFAULT_CONFIG, create_model
+    from inf.train.step import TrainStep, bits_per_dim
+    torch.manual_seed(1)
+    cfg = DEFAULT_CONFIG
+    model = create_model(num_blocks=cfg["num_blocks"], block_size=cfg["block_size"], coupling_width=cfg["coupling_width"],
+                         n_bins=cfg["n_bins"], tail_bound=cfg["tail_bound"]).cuda()
+    x = torch.randint(0, 256, (cfg["batch_size"], 1, 28, 28)).float().cuda()
+    step = TrainStep(model, torch.optim.Adam(model.parameters(), lr=cfg["lr"]), grad_clip_norm=1.0, autocast=True)
+    l0 = float(step(x))
+    l1 = float(step(x))
+    assert np.isfinite(l0) and np.isfinite(l1)
+    assert 0.5 < bits_per_dim(l0, 28 * 28) < 20.0

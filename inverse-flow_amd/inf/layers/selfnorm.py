@@ -193,15 +193,24 @@ class SelfNormConv(ModifiedGradFlowLayer):
 
     def dense_operator(self, input):
         """Dense matrix of the convolution (what the reference builds with inf/utils/toeplitz.py:9-44),
-        obtained by pushing the identity through the HIP conv; fp64 on the CPU like selfnorm.py:175-180."""
+        obtained by pushing the identity through the HIP conv; fp64 on the CPU like selfnorm.py:175-180.
+        Differentiable in weight_fwd while gradients are recorded (the reference's exact-gradient baseline trains
+        through slogdet of this matrix, selfnorm.py:240-246 with experiment.py:161)."""
         C, H, W = input.shape[1:]
         n = C * H * W
         eye = torch.eye(n, device=input.device, dtype=torch.float32).view(n, C, H, W)
-        cols = _h.conv2d(eye, self.weight_fwd.detach().contiguous(), None, self.padding)
+        if torch.is_grad_enabled() and self.weight_fwd.requires_grad:
+            cols = _conv(eye, self.weight_fwd, self.padding)
+        else:
+            cols = _h.conv2d(eye, self.weight_fwd.detach().contiguous(), None, self.padding)
         return cols.flatten(start_dim=1).T.double().cpu()
 
     @mark_expensive
     def logdet(self, input, context=None, compute_expensive=True):
+        if torch.is_grad_enabled() and self.weight_fwd.requires_grad:
+            # part of the loss: a fresh graph per call, never the cached value
+            logabsdet = torch.slogdet(self.dense_operator(input))[1].to(input.dtype).to(input.device)
+            return logabsdet.view(1).expand(len(input))
         if self.logabsdet_dirty:
             self.logabsdet = torch.slogdet(self.dense_operator(input))[1].to(input.dtype).to(input.device)
             self.logabsdet_dirty = False

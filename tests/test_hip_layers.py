@@ -211,6 +211,14 @@ def test_selfnorm_layer_recon_and_exact(H, sym):
                                            x[0].cpu().double())
     ld_ref = torch.slogdet(J.reshape(256, 256))[1]
     np.testing.assert_allclose(host(ld)[0], float(ld_ref), atol=1e-4)
+    # the exact log-det is part of the loss of the exact-gradient baseline (experiment.py:161): its gradient reaches
+    # weight_fwd and equals that of slogdet of the dense operator (selfnorm.py:240-246)
+    layer.weight_fwd.grad = None
+    layer.logdet(x, compute_expensive=True)[0].backward()
+    w64 = layer.weight_fwd.detach().cpu().double().requires_grad_(True)
+    eye = torch.eye(256, dtype=torch.float64).view(256, 4, 8, 8)
+    torch.slogdet(torch.nn.functional.conv2d(eye, w64, None, 1, 1).flatten(start_dim=1).T)[1].backward()
+    assert rel_err(host(layer.weight_fwd.grad), w64.grad.numpy()) < 1e-4
     fc = SelfNormFC(12, 12).cuda()
     xf = torch.randn(5, 12, device="cuda")
     of, ldf = fc(xf, compute_expensive=True)

@@ -79,8 +79,15 @@ size_t ifl_workspace_bytes(int op, int B, int C, int H, int W, int KH, int KW, u
  * passed unchanged to every scan call of ONE stream (launches that use a block must not overlap in time; its contents --
  * the mailbox and per-image launch generations -- advance on the device, so it is valid under graph replay).
  * scan_state = NULL: one workgroup per image; results are bit-identical either way.
+ *
+ * The same block serves the wide layers (64 < C <= 256, H <= 16, W <= 32): there a team of C/16 workgroups sweeps all
+ * anti-diagonals of 16 image columns inside ONE launch and synchronises through generation-numbered flags kept here;
+ * scan_state = NULL (or IFL_FLAG_WHOLE_IMAGE): one launch per anti-diagonal instead.  A launch whose team cannot finish in
+ * bounded time, or whose values leave the fp16 range, is redone by the exact fp32 scan within the same call; the block
+ * counts such launches in a 64-bit word at byte offset ifl_scan_state_voided_offset() (telemetry, read-only for callers).
  */
 size_t ifl_scan_state_bytes(void);
+size_t ifl_scan_state_voided_offset(void);
 
 /*
  * z = A^-1 x -- the layer's forward pass x -> z.

@@ -88,11 +88,12 @@ static int check_shape(const char *fn, int B, int C, int H, int W, int KH, int K
 // buffers that may hold MFMA-packed weights are sized for the padded channel count (scan_mfma.hip)
 static size_t cpad(int C) { return C <= 64 ? (size_t)mfma_padded_channels(C) : (size_t)C; }
 
-static size_t fold_bytes(int B, int C, int KH, int KW)
+static size_t fold_bytes(int B, int C, int H, int W, int KH, int KW)
 {
     const size_t cp = cpad(C);
+    const Geom g = make_geom(B, C, H, W, KH, KW, IFL_ORDER_TL, 0);
     return align_up(cp * cp * sizeof(double), 256) + 2 * align_up((size_t)KH * KW * cp * cp * sizeof(float), 256) +
-           align_up(((size_t)B + 1) * sizeof(int), 256) + 1024;
+           align_up(((size_t)B + 1) * sizeof(int), 256) + 1024 + align_up(scan_team_ws_bytes(g), 256);
 }
 
 // out = conv(in, w) + bias, same-size or general: the MFMA kernel where it applies (needs `pack` bytes of
@@ -158,7 +159,8 @@ static CarryView carry_view(void *carry, int C, int KH, int KW)
 static bool carry_usable(const Geom &g, unsigned flags)
 {
     static float dummy_aligned __attribute__((aligned(16)));
-    return !(flags & (IFL_FLAG_NO_MFMA | IFL_FLAG_EXACT_F32)) && scan_mfma_supported(g, &dummy_aligned, &dummy_aligned);
+    return !(flags & (IFL_FLAG_NO_MFMA | IFL_FLAG_EXACT_F32)) &&
+           (scan_mfma_supported(g, &dummy_aligned, &dummy_aligned) || scan_team_supported(g));
 }
 
 // fold + scan (shared by inverse and dx): z = scan(x) for the operator or its adjoint.
@@ -178,10 +180,42 @@ static int run_scan(const float *x, const float *w, float *z, const Geom &g, int
     if (amax_valid) *amax_valid = false;
     const int rh = g.flipH ^ (transposed ? 1 : 0), rw = g.flipW ^ (transposed ? 1 : 0);
     const bool usable = carry_usable(g, flags);
-    const bool mfma = usable && scan_mfma_supported(g, x, z);
+    const bool team_shape = usable && scan_team_supported(g);
+    const bool mfma = usable && !team_shape && scan_mfma_supported(g, x, z);
     CarryView co{}, ci{};
     if (carry_out && usable) co = carry_view(carry_out, g.C, g.KH, g.KW);
     if (carry_in && usable) ci = carry_view(carry_in, g.C, g.KH, g.KW);
+    if (team_shape) {
+        // wide layers: the fold of this file's route serves both its resident scan and the launch-per-diagonal one
+        char *extra = cv.take<char>(scan_team_ws_bytes(g));
+        if (!cv.ok()) IFL_FAIL(IFL_EWORKSPACE, "workspace too small: need %zu bytes, have %zu", cv.off, cv.cap);
+        const void *pack = wf;
+        const float *pack32 = wf2;
+        {
+            ProfScope ps(IFL_PROF_FOLD, s);
+            if (co.zmax) {
+                if ((rc = launch_fold_team(w, extra, g, transposed, 2, wf, wf2, co.adj_pack, co.adj_wf32, co.zmax, co.dxmax, s)))
+                    return rc;
+            } else if (ci.zmax) {
+                pack = ci.adj_pack;
+                pack32 = ci.adj_wf32;
+            } else if ((rc = launch_fold_team(w, extra, g, transposed, 1, wf, wf2, nullptr, nullptr, nullptr, nullptr, s))) {
+                return rc;
+            }
+        }
+        ProfScope ps(IFL_PROF_SCAN, s);
+        if (scan_state && !(flags & IFL_FLAG_WHOLE_IMAGE) && x != z) {
+            if ((uintptr_t)scan_state & 255) IFL_FAIL(IFL_EINVAL, "scan_state must be 256-byte aligned");
+            unsigned *amax = co.zmax ? co.zmax : (ci.zmax ? ci.dxmax : nullptr);
+            if (amax_valid) *amax_valid = amax != nullptr;
+            void *wide_state = (char *)scan_state + align_up(scan_duo_state_bytes(), 256);
+            if ((rc = launch_scan_team(x, pack, z, g, rh, rw, extra, wide_state, ovf, amax, s))) return rc;
+            // (a no-op unless the launch gave up or a value left the fp16 range: then exact fp32 from x)
+            return launch_scan_general(x, pack32, z, g, rh, rw, s, ovf, 0);
+        }
+        if (scan_wide_supported(g) && x != z) return launch_scan_wide(x, pack32, z, g, rh, rw, s);
+        return launch_scan_general(x, pack32, z, g, rh, rw, s);
+    }
     if (co.zmax) {
         // one launch folds both directions (needed even if this call's pointers force the general scan)
         ProfScope ps(IFL_PROF_FOLD, s);
@@ -271,12 +305,12 @@ size_t ifl_workspace_bytes(int op, int B, int C, int H, int W, int KH, int KW, u
     switch (op) {
     case IFL_OP_INVERSE:
     case IFL_OP_DY:
-        return fold_bytes(B, C, KH, KW);
+        return fold_bytes(B, C, H, W, KH, KW);
     case IFL_OP_FORWARD:
         return wbytes;
     case IFL_OP_BACKWARD:
         // fold + (dx when the caller passes none) + (A z and mixed gradient for the recon term) + dW partials
-        return fold_bytes(B, C, KH, KW) + wbytes + 3 * n + wgrad_mfma_workspace_bytes(B, C, H, KH, KW) +
+        return fold_bytes(B, C, H, W, KH, KW) + wbytes + 3 * n + wgrad_mfma_workspace_bytes(B, C, H, KH, KW) +
                wgrad_small_workspace_bytes(B < 0 ? 0 : B, C, KH, KW) + 512;
     case IFL_OP_DW:
         return wgrad_mfma_workspace_bytes(B, C, H, KH, KW) + wgrad_small_workspace_bytes(B < 0 ? 0 : B, C, KH, KW) + 512;
@@ -285,7 +319,9 @@ size_t ifl_workspace_bytes(int op, int B, int C, int H, int W, int KH, int KW, u
     }
 }
 
-size_t ifl_scan_state_bytes(void) { return scan_duo_state_bytes(); }
+size_t ifl_scan_state_bytes(void) { return align_up(scan_duo_state_bytes(), 256) + scan_wide_state_bytes(); }
+
+size_t ifl_scan_state_voided_offset(void) { return align_up(scan_duo_state_bytes(), 256) + scan_wide_voided_offset(); }
 
 size_t ifl_carry_bytes(int C, int KH, int KW)
 {
@@ -351,6 +387,13 @@ static int dw_impl(const float *z, const float *dx, float *dw, int B, int C, int
             return launch_wgrad_mfma(dx, z, dw, wws, B, C, H, W, KH, KW, pt, pl, -1.0f, g.general_diag ? 2 : 1, dkh,
                                      dkw, amax_dx, amax_z, s);
         IFL_FAIL(IFL_EWORKSPACE, "ifl_dw_f32: workspace too small: need %zu bytes, have %zu", cv.off, cv.cap);
+    }
+    if (!(flags & (IFL_FLAG_NO_MFMA | IFL_FLAG_EXACT_F32)) && wgrad_w8_supported(B, C, H, W, KH, KW, pt, pl, dx, z)) {
+        Carver cv(ws, ws_bytes);
+        void *wws = cv.take<char>(256);
+        if (cv.ok())
+            return launch_wgrad_w8(dx, z, dw, wws, B, C, H, KH, KW, pt, pl, -1.0f, g.general_diag ? 2 : 1, dkh, dkw, amax_dx,
+                                   amax_z, s);
     }
     if (wgrad_small_supported(B, C, H, W, KH, KW)) {
         Carver cv(ws, ws_bytes);

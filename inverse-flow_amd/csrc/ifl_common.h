@@ -166,6 +166,27 @@ int launch_wgrad_small(const float *gz, const float *x, float *dw, void *ws, int
 bool scan_wide_supported(const Geom &g);
 int launch_scan_wide(const float *x, const float *wf, float *z, const Geom &g, int rh, int rw, hipStream_t s);
 
+// ---- wide layers, one resident launch (wide.hip): 64 < C <= 256, C % 32 == 0, H <= 16, W <= 32, K in {2x2,3x3} --------
+// A team of C/16 workgroups per tile of 16 columns sweeps all diagonals inside one launch, exchanging each diagonal's
+// results through `ws`, synchronised by generation-numbered flags in the caller's scan state.
+bool scan_team_supported(const Geom &g);
+size_t scan_team_ws_bytes(const Geom &g); // compact L, block inverses, exchange buffer
+size_t scan_wide_state_bytes();           // this route's part of the scan state (behind the duo scan's)
+size_t scan_wide_voided_offset();         // byte offset, inside that part, of the 64-bit count of voided launches
+// fold direction dir0 (0 operator, 1 adjoint) -> pack0 / wf0 (fp32 left fold wf[t][kc][c]); ndir = 2: also the other
+// direction -> pack1 / wf1.  zero0 / zero1: optional words cleared by the launch.
+int launch_fold_team(const float *w, void *ws, const Geom &g, int dir0, int ndir, void *pack0, float *wf0, void *pack1,
+                     float *wf1, unsigned *zero0, unsigned *zero1, hipStream_t s);
+// gate: B ints written by the launch (1 -> redo the batch with the general scan on the fp32 fold); state: the wide part
+int launch_scan_team(const float *x, const void *pack, float *z, const Geom &g, int rh, int rw, void *ws, void *state,
+                     int *gate, unsigned *amax, hipStream_t s);
+// weight gradient for W = 8, C > 64 (C % 16 == 0); ws: 256 bytes
+bool wgrad_w8_supported(int B, int C, int H, int W, int KH, int KW, int pt, int pl, const void *gz, const void *x);
+int launch_wgrad_w8(const float *gz, const float *x, float *dw, void *ws, int B, int C, int H, int KH, int KW, int pt, int pl,
+                    float scale, int mask_mode, int mkh, int mkw, const unsigned *amax_gz, const unsigned *amax_x,
+                    hipStream_t s);
+int launch_absmax2(const float *a, const float *b, size_t n, unsigned *out, hipStream_t s); // out[0], out[1]
+
 // ---- general (any C, any K) VALU kernels (scan_general.hip, conv_general.hip) ----------------
 size_t scan_general_lds_bytes(const Geom &g);
 // z = scan(x) with folded taps wf; pixel reflection (rh, rw) applied to both x and z addressing.

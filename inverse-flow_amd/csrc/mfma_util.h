@@ -66,4 +66,24 @@ __device__ __forceinline__ void lgkm_wait_n(int n)
     __builtin_amdgcn_sched_barrier(0); // nothing that consumes the data may be scheduled above the wait
 }
 
+// power of two s with s*max in [2^6, 2^7)  (1 if max is 0 or not finite)
+__device__ __forceinline__ float pow2_scale(unsigned maxbits)
+{
+    const int e = (int)((maxbits >> 23) & 0xff);
+    if (maxbits == 0u || e == 0xff) return 1.0f;
+    int se = 127 + 6 - (e - 127); // exponent field of the scale
+    se = se < 1 ? 1 : (se > 254 ? 254 : se);
+    return __uint_as_float((unsigned)se << 23);
+}
+
+// Split fp16 keeps 22 bits below each tensor's maximum.  Tensors that have grown by 2^24 or more along the sweep (an
+// ill-conditioned layer: max|z| or max|dx| >= 1.7e7 for inputs of order one) peak in opposite corners, so that the
+// products that make up dW pair the large entries of one with the small ones of the other: there the contraction is
+// done in plain fp32 instead (by the reduce kernel).  Also taken when a maximum is not finite.
+__device__ __forceinline__ bool wgrad_wide_range(unsigned a_bits, unsigned b_bits)
+{
+    const unsigned m = a_bits > b_bits ? a_bits : b_bits;
+    return m >= 0x4B800000u; // 2^24 as a float bit pattern (non-negative floats order like unsigned; Inf/NaN above)
+}
+
 } // namespace ifl

@@ -24,6 +24,7 @@
 // tools/mfma_f16_denorm_probe.hip) after a power-of-two per-tensor prescale that puts max|v| at 2^6,
 // three MFMAs per k-step (hi*hi + hi*lo + lo*hi), fp32 accumulation.
 #include "ifl_common.h"
+#include "mfma_util.h"
 #include <type_traits>
 #include <stdlib.h>
 
@@ -74,26 +75,6 @@ __global__ __launch_bounds__(256) void k_absmax2(const float *__restrict__ a, co
         atomicMax(out + 0, __float_as_uint(ma));
         atomicMax(out + 1, __float_as_uint(mb));
     }
-}
-
-// power of two s with s*max in [2^6, 2^7)  (1 if max is 0 or not finite)
-__device__ __forceinline__ float pow2_scale(unsigned maxbits)
-{
-    const int e = (int)((maxbits >> 23) & 0xff);
-    if (maxbits == 0u || e == 0xff) return 1.0f;
-    int se = 127 + 6 - (e - 127); // exponent field of the scale
-    se = se < 1 ? 1 : (se > 254 ? 254 : se);
-    return __uint_as_float((unsigned)se << 23);
-}
-
-// Split fp16 keeps 22 bits below each tensor's maximum.  Tensors that have grown by 2^24 or more along the sweep (an
-// ill-conditioned layer: max|z| or max|dx| >= 1.7e7 for inputs of order one) peak in opposite corners, so that the
-// products that make up dW pair the large entries of one with the small ones of the other: there the contraction is
-// done in plain fp32 instead (by the reduce kernel).  Also taken when a maximum is not finite.
-__device__ __forceinline__ bool wgrad_wide_range(unsigned a_bits, unsigned b_bits)
-{
-    const unsigned m = a_bits > b_bits ? a_bits : b_bits;
-    return m >= 0x4B800000u; // 2^24 as a float bit pattern (non-negative floats order like unsigned; Inf/NaN above)
 }
 
 __device__ __forceinline__ void split8(const floatx4 &v0, const floatx4 &v1, float s, half8 &hi, half8 &lo)
@@ -522,15 +503,27 @@ int launch_absmax(const float *a, size_t n, unsigned *out, hipStream_t s)
     return IFL_OK;
 }
 
+int launch_absmax2(const float *a, const float *b, size_t n, unsigned *out, hipStream_t s)
+{
+    IFL_HIP(hipMemsetAsync(out, 0, 2 * sizeof(unsigned), s));
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_absmax2, dim3((unsigned)blocks), dim3(256), 0, s, a, b, n, out);
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+
 bool wgrad_mfma_supported(int B, int C, int H, int W, int KH, int KW, int pt, int pl, const void *gz, const void *x)
 {
-    if (!(C == 32 || C == 64)) return false;
+    if (!(C == 32 || C == 64 || C == 128 || C == 256)) return false; // (wide layers: corner pads only, below)
     if (!(W == 16 || W == 32)) return false;
     if (KH < 1 || KH > 3 || KW < 1 || KW > 3 || KH != KW) return false;
     if (!(KH == 3 || KH == 2)) return false;
     const bool corner = (pt == 0 || pt == KH - 1) && (pl == 0 || pl == KW - 1);
     const bool centered = KH == 3 && KW == 3 && pt == 1 && pl == 1; // SelfNormConv's "same" padding
     if (!corner && !centered) return false;
+    if (C > 64 && centered) return false;
     if (KH == 1 || KW == 1) return false;
     if (B < 1 || H < 1) return false;
     if (((uintptr_t)gz | (uintptr_t)x) & 15) return false;
@@ -604,6 +597,14 @@ int launch_wgrad_mfma(const float *gz, const float *x, float *dw, void *ws, int 
     IFL_CASE(64, 2, 1)
     IFL_CASE(32, 2, 2)
     IFL_CASE(32, 2, 1)
+    IFL_CASE(128, 3, 2)
+    IFL_CASE(128, 3, 1)
+    IFL_CASE(256, 3, 2)
+    IFL_CASE(256, 3, 1)
+    IFL_CASE(128, 2, 2)
+    IFL_CASE(128, 2, 1)
+    IFL_CASE(256, 2, 2)
+    IFL_CASE(256, 2, 1)
 #undef IFL_CASE
 #define IFL_CASE(CC, KK, NN)                                                                                               \
     if (C == CC && KH == KK && W == 16 * NN && centered)                                                                    \

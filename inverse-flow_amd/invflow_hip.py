@@ -37,6 +37,7 @@ SIGNATURES = {
     "ifl_unit_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp, _vp]),
     "ifl_carry_bytes": (_sz, [_i, _i, _i]),
     "ifl_scan_state_bytes": (_sz, []),
+    "ifl_scan_state_voided_offset": (_sz, []),
     "ifl_forward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
     "ifl_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp, _vp]),
     "ifl_dw_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
@@ -200,6 +201,16 @@ def scan_state(dev):
         torch.cuda.current_stream(dev).synchronize()  # (the zero fill is complete before any launch can see the block)
     _scan_states[key] = st
     return st
+
+
+def scan_voided(dev):
+    """How many wide-layer launches of this (device, stream)'s scan state were redone by the exact fp32 scan (telemetry
+    word of the block, include/invflow.h); 0 when no block exists yet."""
+    st = scan_state(dev)
+    if st is None:
+        return 0
+    off = int(lib().ifl_scan_state_voided_offset())
+    return int(st[off:off + 8].view(torch.int64).item())
 
 
 def new_carry(w):

@@ -478,3 +478,79 @@ def test_scan_state_is_caller_owned(H):
     assert b"must not alias" in L.ifl_last_error()
     with pytest.raises(RuntimeError, match="must not alias"):
         H.inverse(x, w, out=x)
+
+
+# ---------------------------------------------------------------------------------------------
+# wide layers (64 < C <= 256): the resident team scan, its fold and the W = 8 weight gradient (csrc/wide.hip)
+# ---------------------------------------------------------------------------------------------
+WIDE = [
+    # B, C, H, W, K, order, diag
+    (16, 256, 8, 8, 3, "TL", 0),   # BASELINE configs[4]: the C = 256 layers at the per-GPU batch
+    (3, 256, 8, 8, 3, "BR", 1),
+    (40, 256, 8, 8, 3, "TR", 0),   # more tiles than teams: several sweeps per team
+    (5, 128, 16, 16, 3, "BL", 0),  # one image per tile
+    (7, 96, 7, 5, 2, "TR", 1),     # ragged: H not a power of two, a partly filled tile
+    (9, 192, 4, 8, 2, "TL", 0),    # four images per tile
+    (2, 160, 3, 20, 3, "BR", 0),
+]
+
+
+@pytest.mark.parametrize("case", WIDE, ids=lambda c: "b%dc%d_%dx%d_k%d_%s_d%d" % c)
+def test_wide_layers(H, oracle, case):
+    B, C, Hh, Ww, K, order, diag = case
+    rng = np.random.default_rng(4000 + WIDE.index(case))
+    x = rng.standard_normal((B, C, Hh, Ww)).astype(np.float32)
+    g = rng.standard_normal((B, C, Hh, Ww)).astype(np.float32)
+    w = _weights(rng, C, K, K, "0.01", order, oracle, diag).astype(np.float32)
+    fl = H.FLAG_GENERAL_DIAG if diag else 0
+    xo, go, wo = x.astype(np.float64), g.astype(np.float64), w.astype(np.float64)
+    z_o = oracle.inverse(xo, wo, diag, order, nthreads=8)
+    u_o = oracle.dy(go, wo, diag, order, nthreads=8)
+    dw_o = oracle.dw(z_o, u_o, (K, K), diag, order, nthreads=8)
+    xd, gd, wd = dev(x), dev(g), dev(w)
+    for use_carry in (False, True):
+        carry = H.new_carry(wd) if use_carry else None
+        z = H.inverse(xd, wd, order, fl, carry=carry)
+        assert rel_err(host(z), z_o) < TOL
+        dx, dw, _ = H.backward(gd, z, wd, order, fl, carry=carry)
+        assert rel_err(host(dx), u_o) < TOL
+        assert rel_err(host(dw), dw_o) < TOL
+        m = oracle.mask(C, K, K, diag, order)
+        assert np.all(host(dw)[m == 0] == 0)
+    # the launch-per-diagonal route (no scan state in use) gives the same answer within the tolerance
+    z1 = H.inverse(xd, wd, order, fl | H.FLAG_WHOLE_IMAGE)
+    assert rel_err(host(z1), z_o) < TOL
+    # twice on the same stream: flags of the previous launch are stale by their generation, not by a clear
+    z2 = H.inverse(xd, wd, order, fl)
+    assert torch.equal(z2, z)
+
+
+def test_wide_layers_beyond_fp16_range(H, oracle):
+    """values beyond the fp16 range (here: the input itself) void the launch: the gated fp32 scan redoes the batch"""
+    rng = np.random.default_rng(77)
+    B, C, Hh, Ww, K = 4, 256, 8, 8, 3
+    x = (rng.standard_normal((B, C, Hh, Ww)) * 1.0e5).astype(np.float32)
+    w = _weights(rng, C, K, K, "0.01", "TL", oracle).astype(np.float32)
+    z_o = oracle.inverse(x.astype(np.float64), w.astype(np.float64), 0, "TL", nthreads=8)
+    z = H.inverse(dev(x), dev(w))
+    assert rel_err(host(z), z_o) < TOL
+    g = rng.standard_normal((B, C, Hh, Ww)).astype(np.float32)
+    u_o = oracle.dy(g.astype(np.float64), w.astype(np.float64), 0, "TL", nthreads=8)
+    dx, dw, _ = H.backward(dev(g), z, dev(w))
+    assert rel_err(host(dx), u_o) < TOL
+    assert rel_err(host(dw), oracle.dw(z_o, u_o, (K, K), 0, "TL", nthreads=8)) < TOL
+
+
+@pytest.mark.parametrize("pad", [(2, 2), (0, 0), (2, 0), (0, 2)], ids=lambda p: "p%d%d" % p)
+def test_wide_weight_gradient_pieces(H, oracle, pad):
+    """the W = 8 weight gradient as a plain convolution weight gradient, every padding corner"""
+    rng = np.random.default_rng(5)
+    B, C, Hh, Ww, K = 6, 128, 6, 8, 3
+    x = rng.standard_normal((B, C, Hh, Ww)).astype(np.float32)
+    gz = rng.standard_normal((B, C, Hh, Ww)).astype(np.float32)
+    # corner pads as the layer uses them: (pt, pl) in {0, K-1}; conv2d_wgrad takes symmetric pads only, so compare through
+    # the layer call: dW = -wgrad(dx, z) with the order that has this corner
+    order = {(2, 2): "TL", (2, 0): "TR", (0, 2): "BL", (0, 0): "BR"}[pad]
+    dw = H.dw_from(dev(x), dev(gz), (K, K), order)
+    dw_o = oracle.dw(x.astype(np.float64), gz.astype(np.float64), (K, K), 0, order, nthreads=8)
+    assert rel_err(host(dw), dw_o) < TOL

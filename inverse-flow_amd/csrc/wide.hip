@@ -73,19 +73,32 @@ __device__ __forceinline__ float wide_l_entry(const float *w, int i, int k, int 
 }
 
 // ---- prep: compact L per direction, inverses of its 16 x 16 diagonal blocks ------------------------------------------
-// grid (C/16, ndir), 256 threads.  lc[dir][i][k] floats, dinv[dir][bi][r][c] doubles.
+// grid (C/16, ndir, KH*KW), 256 threads; z = 0: lc[dir][i][k permuted inside groups of 16] floats, dinv[dir][bi][r][c] doubles.
+// Also rt[dir][t][c][kc] = W_t[c][kc] (operator) / W_t[kc][c] (adjoint): the right-hand sides of the fold, tap-major, so that
+// its lanes read consecutive floats (in the layer's layout a tap's entries are 36 bytes apart).
 __global__ __launch_bounds__(256) void k_wide_prep(const float *__restrict__ w, float *__restrict__ lc, double *__restrict__ dinv,
-                                                   Geom g, int dir0, unsigned *zero0, unsigned *zero1)
+                                                   float *__restrict__ rt, Geom g, int dir0, unsigned *zero0, unsigned *zero1)
 {
     const int C = g.C, bi = blockIdx.x, dir = dir0 + blockIdx.y, slot = blockIdx.y;
+    if (blockIdx.z > 0) { // tap t of rows 16 bi .. + 15, tap-major
+        const int NS = g.KH * g.KW, t = blockIdx.z, dh = t / g.KW, dw = t % g.KW;
+        float *r = rt + ((size_t)slot * NS + t) * C * C;
+        for (int idx = threadIdx.x; idx < 16 * C; idx += 256) {
+            const int kc = idx % C, c = 16 * bi + idx / C;
+            r[(size_t)c * C + kc] = dir ? w[wide_w_index(kc, c, dh, dw, g)] : w[wide_w_index(c, kc, dh, dw, g)];
+        }
+        return;
+    }
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         if (zero0) *zero0 = 0u;
         if (zero1) *zero1 = 0u;
     }
     float *l = lc + (size_t)slot * C * C;
+    // position p = 4 lk + c4 of a group of 16 columns holds column 4 c4 + lk: a lane's float4 at 4 lk is then its
+    // A-operand element of the group's four MFMA k-chunks (k = 4 c4 + lk)
     for (int idx = threadIdx.x; idx < 16 * C; idx += 256) {
-        const int i = 16 * bi + idx / C, k = idx % C;
-        l[(size_t)i * C + k] = wide_l_entry(w, i, k, dir, g);
+        const int i = 16 * bi + idx / C, p = idx % C, k = (p & ~15) + 4 * (p & 3) + ((p >> 2) & 3);
+        l[(size_t)i * C + p] = wide_l_entry(w, i, k, dir, g);
     }
     // the diagonal block itself, staged for the sixteen column solves
     __shared__ float blk[16][17];
@@ -106,8 +119,12 @@ __global__ __launch_bounds__(256) void k_wide_prep(const float *__restrict__ w, 
     }
 }
 
-// ---- fold: X = L^-1 [I | W_1 | ... ] for 16 columns per wave ---------------------------------------------------------
-// grid (C/16 column tiles, KH*KW taps, ndir), 64 threads, C*16 doubles of LDS.
+// ---- fold: X = L^-1 [I | W_1 | ... ] for 16 columns per workgroup -----------------------------------------------------
+// grid (C/16 column tiles, KH*KW taps, ndir), 256 threads, C*17 doubles of LDS.
+// Right-looking blocked substitution on the fp64 matrix cores (16x16x4): block row bi is finished by the inverse of its
+// diagonal block (the wave that owns it: block rows go round the four waves), published through LDS, then every later
+// block row takes its update -L[i][bi] X[bi] in its owner's accumulator.  Per block row one barrier and eight
+// dependent MFMAs; a wave's operands are loaded three steps ahead.
 // Outputs per direction: wf32[t][kc][c] (fp32 left fold, what the general scan takes) and the scan's register image
 //   pack[ct][v][t][hl][lane] (16 B each): lane (m, q) = rows c = 16 ct + m, input channels kc = 32 v + 8 q .. + 7,
 //   +Wf_0, -Wf_t, hi = fp16(v), lo = fp16((v - hi) * 2048).
@@ -115,70 +132,109 @@ struct WideFoldOut {
     float *wf32[2];
     uintx4 *pack[2];
 };
-__global__ __launch_bounds__(64) void k_wide_fold(const float *__restrict__ w, const float *__restrict__ lc,
-                                                  const double *__restrict__ dinv, WideFoldOut out, Geom g, int dir0)
+__global__ __launch_bounds__(256) void k_wide_fold(const float *__restrict__ rt, const float *__restrict__ lc,
+                                                   const double *__restrict__ dinv, WideFoldOut out, Geom g, int dir0)
 {
-    extern __shared__ double xs[]; // [C][16]: row = solve-order index, column = right-hand side
+    extern __shared__ double xs[]; // [C][17]: row = solve-order index, column = right-hand side
     const int C = g.C, NBK = C / 16, NS = g.KH * g.KW, NW = C / 32;
     const int jt = blockIdx.x, t = blockIdx.y, slot = blockIdx.z, dir = dir0 + slot;
-    const int dh = t / g.KW, dw = t % g.KW;
-    const int lane = threadIdx.x, li = lane % 16, lk = lane / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane % 16, lk = lane / 16;
     const float *l = lc + (size_t)slot * C * C;
     const double *di = dinv + (size_t)slot * NBK * 256;
     const int kc = 16 * jt + li; // this lane's right-hand-side column = input channel of the tap
-    for (int bi = 0; bi < NBK; ++bi) {
-        doublex4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-        // row 16 bi + li of L, columns 0 .. 16 bi - 1: all loads first (16 bytes per lane and 16 columns), then the chain.
-        // Within a group of 16 columns lane group lk takes columns 4 lk .. 4 lk + 3, one per MFMA (any order of the
-        // reduction index does, as long as both operands use it).
-        const float *lrow = l + (size_t)(16 * bi + li) * C + 4 * lk;
-        floatx4 la[15];
+    const float *rtap = rt + ((size_t)slot * NS + t) * C * C;
+    constexpr int XP = 17; // row pitch of xs in doubles (odd: the column reads of the output stage spread over the banks)
+    // this wave's block rows: wv, wv + 4, wv + 8, wv + 12 -> accumulator slot i / 4
+    doublex4 acc[4];
 #pragma unroll
-        for (int j = 0; j < 15; ++j)
-            if (j < bi) la[j] = *(const floatx4 *)(lrow + 16 * j);
+    for (int i = 0; i < 4; ++i) acc[i] = doublex4{0.0, 0.0, 0.0, 0.0};
+    constexpr int PFD = 3;
+    floatx4 lb[PFD + 1][4];
+    doublex4 rr, dd;
+    auto fetch_l = [&](auto bi_c) { // column block BI of L for this wave's later block rows
+        constexpr int BI = decltype(bi_c)::value;
+        if (BI >= NBK) return;
 #pragma unroll
-        for (int j = 0; j < 15; ++j)
-            if (j < bi) {
-                const double *xr_ = xs + (size_t)(16 * j + 4 * lk) * 16 + li;
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)la[j][0], xr_[0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)la[j][1], xr_[16], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)la[j][2], xr_[32], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)la[j][3], xr_[48], acc1, 0, 0, 0);
-            }
-        // right-hand side of rows 16 bi + 4 v + lk (solve order), column kc
-        doublex4 s;
+        for (int a4 = 0; a4 < 4; ++a4) {
+            const int i = 4 * a4 + wv;
+            if (i > BI && i < NBK) lb[BI % (PFD + 1)][a4] = *(const floatx4 *)(l + (size_t)(16 * i + li) * C + 16 * BI + 4 * lk);
+        }
+    };
+    auto fetch_own = [&](int bi) { // right-hand side and diagonal-block inverse of a block row this wave owns
+        if (bi >= NBK) return;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int i = 16 * bi + 4 * v + lk, c = dir ? C - 1 - i : i;
-            double r;
-            if (t == 0) r = (c == kc) ? 1.0 : 0.0;
-            else r = (double)(dir ? w[wide_w_index(kc, c, dh, dw, g)] : w[wide_w_index(c, kc, dh, dw, g)]);
-            s[v] = r - (acc0[v] + acc1[v]);
+            rr[v] = t == 0 ? ((c == kc) ? 1.0 : 0.0) : (double)rtap[(size_t)c * C + kc];
+            dd[v] = di[((size_t)bi * 16 + li) * 16 + 4 * v + lk];
         }
-        doublex4 res = {0.0, 0.0, 0.0, 0.0};
+    };
+    auto step = [&](auto bi_c) {
+        constexpr int BI = decltype(bi_c)::value;
+        if (BI >= NBK) return; // (uniform)
+        if constexpr (BI + PFD < 16) fetch_l(std::integral_constant<int, BI + PFD>{});
+        if (wv == BI % 4) {
+            doublex4 sv;
 #pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4)
-            res = __builtin_amdgcn_mfma_f64_16x16x4f64(di[((size_t)bi * 16 + li) * 16 + 4 * k4 + lk], s[k4], res, 0, 0, 0);
+            for (int v = 0; v < 4; ++v) sv[v] = rr[v] - acc[BI / 4][v];
+            doublex4 res = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int v = 0; v < 4; ++v) xs[(16 * bi + 4 * v + lk) * 16 + li] = res[v];
-        __syncthreads(); // (one wave: orders the LDS writes before the next block row's reads)
-    }
+            for (int k4 = 0; k4 < 4; ++k4) res = __builtin_amdgcn_mfma_f64_16x16x4f64(dd[k4], sv[k4], res, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) xs[(16 * BI + 4 * v + lk) * XP + li] = res[v];
+            fetch_own(BI + 4);
+        }
+        __syncthreads();
+        if (BI + 1 >= NBK) return;
+        double xb[4];
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) xb[c4] = xs[(16 * BI + 4 * c4 + lk) * XP + li];
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) {
+                const int i = 4 * a4 + wv;
+                if (i > BI && i < NBK)
+                    acc[a4] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)lb[BI % (PFD + 1)][a4][c4], xb[c4], acc[a4], 0, 0, 0);
+            }
+    };
+    fetch_own(wv);
+    fetch_l(std::integral_constant<int, 0>{});
+    fetch_l(std::integral_constant<int, 1>{});
+    fetch_l(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{});
+    step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{});
+    step(std::integral_constant<int, 7>{});
+    step(std::integral_constant<int, 8>{});
+    step(std::integral_constant<int, 9>{});
+    step(std::integral_constant<int, 10>{});
+    step(std::integral_constant<int, 11>{});
+    step(std::integral_constant<int, 12>{});
+    step(std::integral_constant<int, 13>{});
+    step(std::integral_constant<int, 14>{});
+    step(std::integral_constant<int, 15>{});
+    __syncthreads();
     // fp32 left fold: wf32[t][kc][c], c contiguous
     float *wf = out.wf32[slot];
-    for (int idx = lane; idx < 16 * C; idx += 64) {
+    for (int idx = tid; idx < 16 * C; idx += 256) {
         const int j = idx / C, c = idx % C, i = dir ? C - 1 - c : c;
-        wf[((size_t)t * C + 16 * jt + j) * C + c] = (float)xs[i * 16 + j];
+        wf[((size_t)t * C + 16 * jt + j) * C + c] = (float)xs[i * XP + j];
     }
-    // the scan's register image: this wave holds input channels 16 jt .. + 15 = half of k-block v = jt / 2
+    // the scan's register image: this workgroup holds input channels 16 jt .. + 15 = half of k-block v = jt / 2
     uintx4 *pk = out.pack[slot];
-    const int v = jt / 2, m = lane % 16, qq = (lane / 16) % 2, q = 2 * (jt % 2) + qq;
+    const int v = jt / 2, m = tid % 16, qq = (tid / 16) % 2, q = 2 * (jt % 2) + qq;
     const double sgn = t == 0 ? 1.0 : -1.0;
-    for (int ct = lane / 32; ct < NBK; ct += 2) {
+    for (int ct = tid / 32; ct < NBK; ct += 8) {
         const int c = 16 * ct + m, i = dir ? C - 1 - c : c;
         half8 hi, lo;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float val = (float)(sgn * xs[i * 16 + 8 * qq + e]);
+            const float val = (float)(sgn * xs[i * XP + 8 * qq + e]);
             const _Float16 h = (_Float16)val;
             hi[e] = h;
             lo[e] = (_Float16)((val - (float)h) * LO_SCALE);
@@ -451,13 +507,15 @@ bool scan_team_supported(const Geom &g)
     return g.C > 64 && g.C <= 256 && g.C % 32 == 0 && g.H <= 16 && g.W <= 32 &&
            ((g.KH == 3 && g.KW == 3) || (g.KH == 2 && g.KW == 2));
 }
-// workspace of the route: compact L (2 directions), block inverses, exchange buffer
+// workspace of the route: compact L (2 directions), block inverses, tap-major right-hand sides, exchange buffer
+static size_t wide_ws_dinv_off(size_t C) { return align_up(2 * C * C * sizeof(float), 256); }
+static size_t wide_ws_rt_off(size_t C) { return wide_ws_dinv_off(C) + align_up(2 * C * 16 * sizeof(double), 256); }
+static size_t wide_ws_exch_off(size_t C, int ns) { return wide_ws_rt_off(C) + align_up(2 * (size_t)ns * C * C * sizeof(float), 256); }
 size_t scan_team_ws_bytes(const Geom &g)
 {
     if (!scan_team_supported(g)) return 0;
     const size_t C = (size_t)g.C;
-    return align_up(2 * C * C * sizeof(float), 256) + align_up(2 * C * 16 * sizeof(double), 256) +
-           align_up((size_t)wide_ntiles(g) * WIDE_NDMAX * (C / 32) * 2 * 1024, 256) + 256;
+    return wide_ws_exch_off(C, g.KH * g.KW) + align_up((size_t)wide_ntiles(g) * WIDE_NDMAX * (C / 32) * 2 * 1024, 256) + 256;
 }
 
 static int device_cu_count()
@@ -474,14 +532,15 @@ int launch_fold_team(const float *w, void *ws, const Geom &g, int dir0, int ndir
 {
     const size_t C = (size_t)g.C;
     float *lc = (float *)ws;
-    double *dinv = (double *)((char *)ws + align_up(2 * C * C * sizeof(float), 256));
+    double *dinv = (double *)((char *)ws + wide_ws_dinv_off(C));
     WideFoldOut out;
     out.wf32[0] = wf0;
     out.wf32[1] = wf1;
     out.pack[0] = (uintx4 *)pack0;
     out.pack[1] = (uintx4 *)pack1;
-    hipLaunchKernelGGL(k_wide_prep, dim3(g.C / 16, ndir), dim3(256), 0, s, w, lc, dinv, g, dir0, zero0, zero1);
-    hipLaunchKernelGGL(k_wide_fold, dim3(g.C / 16, g.KH * g.KW, ndir), dim3(64), C * 16 * sizeof(double), s, w, lc, dinv, out, g,
+    float *rt = (float *)((char *)ws + wide_ws_rt_off(C));
+    hipLaunchKernelGGL(k_wide_prep, dim3(g.C / 16, ndir, g.KH * g.KW), dim3(256), 0, s, w, lc, dinv, rt, g, dir0, zero0, zero1);
+    hipLaunchKernelGGL(k_wide_fold, dim3(g.C / 16, g.KH * g.KW, ndir), dim3(256), C * 17 * sizeof(double), s, rt, lc, dinv, out, g,
                        dir0);
     IFL_HIP(hipGetLastError());
     return IFL_OK;
@@ -504,7 +563,7 @@ int launch_scan_team(const float *x, const void *pack, float *z, const Geom &g, 
     a.pack = (const uintx4 *)pack;
     a.z = z;
     const size_t C = (size_t)g.C;
-    a.exch = (unsigned char *)ws + align_up(2 * C * C * sizeof(float), 256) + align_up(2 * C * 16 * sizeof(double), 256);
+    a.exch = (unsigned char *)ws + wide_ws_exch_off(C, g.KH * g.KW);
     a.st = (WideState *)state;
     a.gate = gate;
     a.amax = amax;

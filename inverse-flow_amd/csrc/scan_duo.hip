@@ -61,6 +61,7 @@ template <int C, int KH, int KW> struct DuoCfg {
     static constexpr int THREADS = 128 * NW;
     static constexpr int G = 4 / NW;       // rows per helper wave that start / finish a quad each step
     static constexpr int PF = 8;           // x quads are requested PF steps before their first use
+    static constexpr int LEAD = 4;         // steps before the first pixel of a tile that takes no hand-off (its first rows: one burst)
 #ifndef IFL_PFH
 #define IFL_PFH 3
 #endif
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
         int Ws = W;
         asm volatile("" : "+s"(Ws));
 
-        auto chain_sweep = [&](const int Hp, const float xscale) {
+        auto chain_sweep = [&](const int Hp, const float xscale, const int dfirst) {
             const bool hval = n < Hp;
             const int ND = Hp + W - 1;
             floatx4 ahi[Cfg::NACC], amid[Cfg::NACC];
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                 (void)ntap;
             };
 
-            int d = -PF;
+            int d = dfirst;
             for (; d < -2; ++d) asm volatile("s_barrier" ::: "memory"); // (the helpers' lead-in: first x quads, first lines)
             for (; d <= ND; ++d) step(d);
             for (; d <= ND + 1; ++d) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -548,7 +549,8 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
         st_rt[1] = __builtin_amdgcn_s_memrealtime();
         st_mt[0] = __builtin_amdgcn_s_memtime();
 #endif
-        chain_sweep(my_part == 1 ? H - 16 : (H < 16 ? H : 16), 1.0f);
+        // (a tile that takes no hand-off has a short lead-in: its helpers start the first rows' loads in one burst)
+        chain_sweep(my_part == 1 ? H - 16 : (H < 16 ? H : 16), 1.0f, my_part == 1 ? -PF : -Cfg::LEAD);
 #ifdef IFL_STAMPS
         st_mt[1] = __builtin_amdgcn_s_memtime();
         st_rt[2] = __builtin_amdgcn_s_memrealtime();
@@ -570,7 +572,7 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
         for (int t = 0; t < ntile; ++t) {
             zero_ring();
             __syncthreads();
-            chain_sweep(split ? (t ? H - 16 : 16) : H, 1.0f / 4096.0f);
+            chain_sweep(split ? (t ? H - 16 : 16) : H, 1.0f / 4096.0f, (split && t) ? -PF : -Cfg::LEAD);
             __syncthreads();
         }
         const int bad2 = __syncthreads_or(rmax < 6.0e4f ? 0 : 1);
@@ -739,6 +741,41 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                         if (k2 - k <= PFR - PFX && RPH * wv + k2 < Hp) n += NIM; // (loaded k2 - k steps later: before the use)
                     behind[k] = n;
                 }
+                // A tile that takes no hand-off starts LEAD steps before its first pixel instead of PFR: the rows the
+                // skipped steps would have loaded (rows 0 .. PFR - LEAD - 1, all of them helper 0's) go out in one burst here.
+                constexpr int LEAD = Cfg::LEAD, NBURST = PFR - LEAD;
+                static_assert(NBURST == 4 && LEAD % 4 == 0 && RPH >= NBURST, "burst = buffers 0..3 of helper 0");
+                const int dfirst = consume ? -PFR : -LEAD;
+                if (!consume && wv == 0 && !(IFL_EXP & 1)) {
+                    if (0 < Hp) rb_load_row<0 * 4 * NIM, NIM>(go, xg + row_off(0));
+                    if (1 < Hp) rb_load_row<1 * 4 * NIM, NIM>(go, xg + row_off(1));
+                    if (2 < Hp) rb_load_row<2 * 4 * NIM, NIM>(go, xg + row_off(2));
+                    if (3 < Hp) rb_load_row<3 * 4 * NIM, NIM>(go, xg + row_off(3));
+#pragma unroll
+                    for (int k = 0; k < NBURST; ++k) {
+                        // younger than row k's loads at its first use (step k - PFX, after that step's load duty): the burst's
+                        // later rows, the rows the loop has loaded since (r = 4 .. k + PFR - PFX, this wave's if RPH = 8), and
+                        // one mailbox store per finished step
+                        int n = 0;
+                        for (int k2 = k + 1; k2 < NBURST; ++k2)
+                            if (k2 < Hp) n += NIM;
+                        if (RPH > NBURST)
+                            for (int r = NBURST; r <= k + PFR - PFX && r < RPH; ++r)
+                                if (r < Hp) n += NIM;
+                        if (publish && mbox) n += k + LEAD - PFX;
+                        behind[k] = n;
+                    }
+                }
+
+                // Every per-step condition is a range of d: one unsigned compare each, "(unsigned)(d - lo) < n" with n = 0
+                // when the sweep does not have that duty (the conditions are wave-uniform; written as conjunctions the
+                // compiler keeps each of them as a 64-bit lane mask and the helper's step is mostly scalar mask algebra)
+                const unsigned n_hin = (consume && mbox) ? (unsigned)(dl_last + 3) : 0u;                  // d in [-2, dl_last]
+                const unsigned n_hout = (publish && mbox) ? (unsigned)(u_last - 13) : 0u;                 // d - 1 in [14, u_last]
+                const unsigned n_zprod = (IFL_EXP & 4) ? 0u : (unsigned)ND;                               // d in [1, ND]
+                const int l_lo = RPH * wv - PFR;                                                          // r = d + PFR in this wave's rows
+                const unsigned n_load = (IFL_EXP & 1) ? 0u : (unsigned)((Hp - RPH * wv) < 0 ? 0 : ((Hp - RPH * wv) < RPH ? (Hp - RPH * wv) : RPH));
+                const bool mb_in = consume && mbox, mb_out = publish && mbox;
 
                 // ---- one step; P = d mod 4 (compile-time: it names the row buffers that are due) ----
                 auto step = [&](auto p_c, const int d) {
@@ -746,9 +783,9 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                     IFL_HSTAMP(6); // (the wait at the end of the previous step)
                     asm volatile("s_barrier" ::: "memory");
                     IFL_HSTAMP(0); // barrier
-                    const bool h_in = consume && mbox && d >= -2 && d <= dl_last && !dead;
-                    const bool h_out = publish && mbox && d - 1 >= 14 && d - 1 <= u_last;
-                    const bool zprod = d >= 1 && d <= ND && !(IFL_EXP & 4);
+                    const bool h_in = (unsigned)(d + 2) < n_hin && !dead;
+                    const bool h_out = (unsigned)(d - 15) < n_hout;
+                    const bool zprod = (unsigned)(d - 1) < n_zprod;
                     // ---- LDS requests whose data the step needs: the mailbox line that landed, the fragments of r_{d-1}
                     floatx4_ hq;
                     if (h_in) {
@@ -773,7 +810,7 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                     // ---- load duty: the row whose first pixel is PFR steps away (this wave's rows come up in consecutive steps)
                     {
                         const int r = d + PFR; // (r mod 4 = P)
-                        if (r >= 0 && r < Hp && r / RPH == wv && !(IFL_EXP & 1)) {
+                        if ((unsigned)(d - l_lo) < n_load) {
                             const char *src = xg + row_off(r);
                             if constexpr (RPH == 4) {
                                 rb_load_row<4 * P * NIM, NIM>(go, src);
@@ -789,7 +826,7 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                         constexpr int KX0 = (P + PFX) & 3;
                         const int r = RPH * wv + KX0 + 4 * j;
                         const int ql = (d + PFX - r) >> 2;
-                        if (r < Hp && ql >= 0 && ql < NQL) { // (wave-uniform)
+                        if ((unsigned)(d + PFX - r) < (r < Hp ? 4u * NQL : 0u)) { // r < Hp && 0 <= ql < NQL (wave-uniform)
                             if (ql == 0) wait_vm(behind[KX0 + 4 * j]); // the row has landed (first use)
                             const int pq = rw ? NQL - 1 - ql : ql;
                             const unsigned la = ldsbase + Cfg::OFF_XS + r * Cfg::XROWB + (ql & 1) * (C * 16) + lc * 16;
@@ -799,7 +836,7 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                     }
                     // ---- the mailbox helper issues exactly one vector-memory operation per step besides its rows:
                     //      the line to be delivered PFH steps from now (lower part) ...
-                    if (consume && mbox && d == -2 - PFH) {
+                    if (mb_in && d == -2 - PFH) {
                         // gate: the first line is requested once the upper part's diagonal 14 + GATE is visible, so that every
                         // later request (one per step, like the upper part's lines) finds its line; the steps before this one
                         // (this tile's first rows are on their way) did not have to wait for the upper part
@@ -813,9 +850,9 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                         st_slow = 0;
 #endif
                     }
-                    if (consume && mbox && !(IFL_EXP & 16)) {
+                    if (mb_in && !(IFL_EXP & 16)) {
                         const int dl = d + PFH;
-                        const bool ok = dl >= -2 && dl <= dl_last;
+                        const bool ok = (unsigned)(dl + 2) < n_hin;
                         const char *line = mb + (size_t)(ok ? dl + 16 : 0) * DUO_LINEB;
                         const unsigned dst = __builtin_amdgcn_readfirstlane(ok ? ldsbase + Cfg::OFF_HALO + (dl & (Cfg::NHL - 1)) * 1024 : dmy);
                         asm volatile("s_mov_b32 m0, %0\n\t"
@@ -862,7 +899,7 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                     IFL_HSTAMP(4); // hand-off in + z product
                     // ---- ... or the line of the diagonal the chain waves finished in the previous step (upper part; a spare
                     //      line takes the steps without one: the operation count stays exact)
-                    if (publish && mbox) {
+                    if (mb_out) {
                         const int u = d - 1;
                         // (zero outside the image: the operator's padding; the ring keeps older pixels there)
                         const bool in = h_out && mlane && (unsigned)(u - mrow) < (unsigned)W;
@@ -877,7 +914,7 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                         constexpr int KZ0 = (P + 3) & 3; // (d - 5) mod 4
                         const int r = RPH * wv + KZ0 + 4 * j;
                         const int ql = (d - 5 - r) >> 2;
-                        if (r < Hp && ql >= 0 && ql < NQL) { // (wave-uniform)
+                        if ((unsigned)(d - 5 - r) < (r < Hp ? 4u * NQL : 0u)) { // r < Hp && 0 <= ql < NQL (wave-uniform)
                             const int pq = rw ? NQL - 1 - ql : ql;
                             const unsigned la = ldsbase + Cfg::OFF_ZQ + r * Cfg::ZROWB + (ql & 1) * (C * 16) + lc * 16;
                             if (j == 0) rb_read_all<4 * KZ0 * NIM, NIM>(0x0101010101010101ull << pq, la);
@@ -909,7 +946,7 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // x quads and z staged by this wave are in LDS
                 };
                 static_assert(PFR % 4 == 0, "the sweep starts at a step that is 0 modulo 4");
-                for (int d = -PFR; d <= ND + 1; d += 4) {
+                for (int d = dfirst; d <= ND + 1; d += 4) {
                     step(std::integral_constant<int, 0>{}, d);
                     if (d + 1 > ND + 1) break;
                     step(std::integral_constant<int, 1>{}, d + 1);

@@ -170,7 +170,7 @@ def train_step_figure(dev, steps=20, warmup=5):
     torch.manual_seed(3)
     model = create_model(num_blocks=cfg["num_blocks"], block_size=cfg["block_size"], coupling_width=cfg["coupling_width"],
                          n_bins=cfg["n_bins"], tail_bound=cfg["tail_bound"]).to(dev)
-    step = TrainStep(model, torch.optim.Adam(model.parameters(), lr=cfg["lr"]), grad_clip_norm=1.0, autocast=True)
+    step = TrainStep(model, torch.optim.Adam(model.parameters(), lr=cfg["lr"]), grad_clip_norm=1.0, autocast=True, graph=True)
     x = torch.randint(0, 256, (cfg["batch_size"], 1, 28, 28), device=dev).float()
     for _ in range(warmup):
         loss = step(x)
@@ -180,9 +180,43 @@ def train_step_figure(dev, steps=20, warmup=5):
         loss = step(x)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    return {"config": "configs[2]: if_glow_mnist L=2, K=16, batch 100, 28x28x1, bf16 autocast, Adam, synthetic uniform-dequantised data",
+    return {"config": "configs[2]: if_glow_mnist L=2, K=16, batch 100, 28x28x1, bf16 autocast, Adam, synthetic uniform-dequantised data; "
+                      "the step (forward, backward, clip, Adam) replayed as one captured graph after %d eager steps" % step.graph_warmup,
             "ms_per_step": ms, "images_per_s": cfg["batch_size"] / (ms * 1e-3), "bits_per_dim": bits_per_dim(float(loss), 28 * 28),
             "parameters": sum(p.numel() for p in model.parameters()), "steps": steps}
+
+
+def wide_layer_figure(dev, steps=50, warmup=10):
+    """BASELINE configs[4]'s channel count: one 3x3 inverse-conv layer of C = 256 on 8x8 at the per-GPU batch 16 (the 100
+    images of inf/if_multiGPU_imagenet32.py:294 over 8 GPUs, rounded up), inverse + fused backward like the headline step.
+    Device time by stream events.  Not part of `value`."""
+    import torch
+    import invflow_hip as H
+    B_, C_, H_, W_, K_ = 16, 256, 8, 8, 3
+    gen = torch.Generator().manual_seed(5)
+    w = torch.zeros(C_, C_, K_, K_)
+    w[:, :, -1, -1] = torch.eye(C_)
+    w = (w + 0.01 * torch.randn(C_, C_, K_, K_, generator=gen)).to(dev)
+    x = torch.randn(B_, C_, H_, W_, generator=gen).to(dev)
+    g = torch.randn(B_, C_, H_, W_, generator=gen).to(dev)
+    z, dx, dw = torch.empty_like(x), torch.empty_like(x), torch.empty_like(w)
+    carry = H.new_carry(w)
+
+    def step():
+        H.inverse(x, w, "TL", 0, out=z, carry=carry)
+        H.backward(g, z, w, "TL", 0, dx_out=dx, dw_out=dw, carry=carry)
+
+    for _ in range(warmup):
+        step()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(steps):
+        step()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / steps
+    return {"config": "one inverse-conv layer 3x3, C=256, 8x8, batch 16, fp32: inverse + fused backward", "ms_per_step": ms,
+            "images_per_s": B_ / (ms * 1e-3), "steps": steps, "voided_launches": H.scan_voided(x.device)}
 
 
 def committed_counters(kernel_us, world):
@@ -356,6 +390,7 @@ def main():
         }
         if world == 1 and not args.no_train_step:
             out["train_step"] = train_step_figure(dev)
+            out["wide_layer"] = wide_layer_figure(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w_host)
         print(json.dumps(out), flush=True)

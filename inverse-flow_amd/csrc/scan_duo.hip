@@ -11,8 +11,9 @@
 //                the 8 tap products (48 MFMAs at C = 64, 3x3), the epilogue r_d = x + acc -> split fp16 -> ring.
 //                No vector-memory instruction, no scalar address arithmetic, no staging of results.
 //   helper waves (wave C/16 + w, the same SIMD as chain wave w at C = 64): everything off the chain -- the z product
-//                z_{d-1} = L^-1 r_{d-1} (6 MFMAs) and its staging, the store of finished z quads, the LDS-DMA of the x
-//                quads needed PF steps ahead, and the hand-off mailbox.  Their scalar, LDS and memory instructions issue
+//                z_{d-1} = L^-1 r_{d-1} (6 MFMAs) and its staging, the image rows (loaded whole into registers PF steps
+//                ahead, x quads handed to the chain waves through LDS, finished z quads taken back, rows stored as whole
+//                lines: see the helper section), and the hand-off mailbox.  Their scalar, LDS and memory instructions issue
 //                through ports the chain wave does not use; measured (tools/two_wave_probe.hip): 1782 cycles per step
 //                for one wave doing both jobs, 1102 for the pair.
 //
@@ -23,7 +24,7 @@
 // and 15 of every finished diagonal as one 1 KiB mailbox line of 8-byte {value, tag} granules (write-through); the
 // lower part's helper 0 prefetches the line by LDS-DMA, checks the tags and writes the rows into row block 0 of its ring
 // (the block that is the zero padding of a whole image) one step before its chain waves read them.  Tags are launch
-// generations kept in a caller-owned block (ifl_scan_state_register): no cleaning, valid under graph replay.  The upper
+// generations kept in the caller's scan state (an argument of the entry points): no cleaning, valid under graph replay.  The upper
 // part waits for nobody; every wait of the lower part is bounded; an image whose hand-off failed or whose r left the
 // fp16 range is redone by the lower part's workgroup alone (both tiles in turn through the same mailbox, x scaled by
 // 2^-12), and beyond that by the exact fp32 body.  Results are bit-identical to the whole-image kernel of scan_mfma.hip.

@@ -47,6 +47,18 @@ class ActNorm(FlowActivationLayer):
         self.log_scale = torch.nn.Parameter(torch.zeros(n_dims))
         torch.nn.init.normal_(self.log_scale)
         self.register_buffer('initialized', torch.tensor(0))
+        # host copy of the flag: reading the buffer costs a device sync per call (and cannot be captured into a graph);
+        # None = unknown (fresh module, or a state dict has just been loaded) -> read the buffer once
+        self._init_seen = None
+
+    def _is_initialized(self):
+        if not self._init_seen:
+            self._init_seen = bool(self.initialized)
+        return self._init_seen
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._init_seen = None
+        return super()._load_from_state_dict(*args, **kwargs)
 
     def _initialize(self, input):
         with torch.no_grad():
@@ -59,13 +71,14 @@ class ActNorm(FlowActivationLayer):
             self.translation.data.copy_(mean)
             self.log_scale.data.copy_(log_std)
             self.initialized.fill_(1)
+            self._init_seen = True
 
     def _views(self, input):
         shape = (1, -1, 1, 1) if input.dim() == 4 else (1, -1)
         return self.translation.view(shape), self.log_scale.view(shape)
 
     def forward(self, input, context=None):
-        if not self.initialized:
+        if not self._is_initialized():
             self._initialize(input)
         if _hip_ok(input):
             return _ActNormFn.apply(input, self.translation, self.log_scale)
@@ -73,7 +86,7 @@ class ActNorm(FlowActivationLayer):
         return (input - translation) * torch.exp(-log_scale), self.logdet(input, context)
 
     def reverse(self, input, context=None):
-        assert self.initialized
+        assert self._is_initialized()
         if _hip_ok(input) and input.dtype == torch.float32 and not torch.is_grad_enabled():
             return H.actnorm(input.contiguous(), self.translation.contiguous(), self.log_scale.contiguous(), reverse=True)
         translation, log_scale = self._views(input)

@@ -40,15 +40,58 @@ def clear_grad(module):
 
 
 class TrainStep:
+    """graph=True: after `graph_warmup` eager steps the whole step -- forward, backward, clip, optimizer -- is captured into
+    one HIP graph and every later call is a copy of the batch into the captured input plus one replay (the step of a
+    small-image Glow is hundreds of short launches: host-bound when issued one by one).  Needs a fixed batch shape, an
+    optimizer that can be captured (Adam/AdamW get capturable=True set here, before their first step) and the gradient
+    bucket; every launch of the library is stream-ordered and allocation-free, so it captures as it is."""
+
     def __init__(self, model, optimizer, add_recon_grad=False, grad_clip_norm=None, grad_clip=None, clear_grads=False,
-                 autocast=False, bucket=True):
+                 autocast=False, bucket=True, graph=False, graph_warmup=3):
         self.model, self.optimizer = model, optimizer
         self.add_recon_grad, self.grad_clip_norm, self.grad_clip = add_recon_grad, grad_clip_norm, grad_clip
         self.clear_grads, self.autocast = clear_grads, autocast
         # every parameter's .grad is a view of one flat buffer: zeroing and the all-reduce are one operation each
         self.bucket = dp.GradBucket(model.parameters()) if bucket else None
+        self.graph, self.graph_warmup = graph, graph_warmup
+        self._calls, self._captured, self._static_x, self._static_loss, self._stream = 0, None, None, None, None
+        if graph:
+            if self.bucket is None:
+                raise ValueError("TrainStep(graph=True) needs the gradient bucket (the gradients' addresses must not move)")
+            for group in optimizer.param_groups:
+                if "capturable" in group:
+                    group["capturable"] = True
 
     def __call__(self, x):
+        if not self.graph or not x.is_cuda:
+            return self._eager(x)
+        if self._captured is None:
+            # eager steps first (data-dependent inits, optimizer state, workspaces) -- on the stream the capture will use, so
+            # that autograd's accumulation nodes and the library's per-stream scan state belong to it
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(x.device)
+            cur = torch.cuda.current_stream(x.device)
+            if self._calls < self.graph_warmup:
+                self._calls += 1
+                self._stream.wait_stream(cur)
+                with torch.cuda.stream(self._stream):
+                    loss = self._eager(x)
+                cur.wait_stream(self._stream)
+                return loss
+            self._static_x = x.clone()
+            torch.cuda.synchronize()
+            self._captured = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._captured, stream=self._stream):
+                self._static_loss = self._eager(self._static_x)
+            self._captured.replay()  # (capturing records the step without running it: this batch's step runs now)
+            return self._static_loss.clone()
+        if x.shape != self._static_x.shape:
+            raise ValueError("TrainStep(graph=True) was captured for batches of shape %s" % (tuple(self._static_x.shape),))
+        self._static_x.copy_(x)
+        self._captured.replay()
+        return self._static_loss.clone()
+
+    def _eager(self, x):
         if self.bucket is not None:
             self.bucket.zero()
         else:

@@ -89,3 +89,25 @@ def test_config3_model_builds_at_its_own_size():
     l1 = float(step(x))
     assert np.isfinite(l0) and np.isfinite(l1)
     assert 0.5 < bits_per_dim(l0, 28 * 28) < 20.0
+
+
+def test_train_step_as_one_graph(fixture):
+    """TrainStep(graph=True): after its eager warm-up the whole step (forward, backward, clip, Adam) is one captured graph;
+    the loss sequence is that of the eager step on the same batches (no dequantisation noise in this model), and a batch of
+    another shape is refused."""
+    from inf.train.step import TrainStep
+    x = torch.from_numpy(fixture["x"]).float().cuda()
+    xs = [x, x * 0.5 + 64.0, x * 0.25 + 128.0]
+    seqs = []
+    for graph in (False, True):
+        torch.manual_seed(0)
+        model = build(fixture)
+        step = TrainStep(model, torch.optim.Adam(model.parameters(), lr=1e-3), grad_clip_norm=1.0, clear_grads=True, graph=graph,
+                         graph_warmup=2)
+        seqs.append([float(step(xs[i % 3])) for i in range(9)])
+        if graph:
+            assert step._captured is not None
+            with pytest.raises(ValueError):
+                step(x[:3])
+    np.testing.assert_allclose(seqs[1], seqs[0], rtol=2e-4)
+    assert seqs[1][-1] < seqs[1][0]

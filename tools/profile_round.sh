@@ -9,12 +9,14 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done"
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-events > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-events --no-train-step > $OUT/stats.log 2>&1
 echo "stats done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o fetch -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o fetch -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events --no-train-step > $OUT/pmc_fetch.log 2>&1
 echo "fetch done"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o write -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o write -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events --no-train-step > $OUT/pmc_write.log 2>&1
 echo "write done"
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT --kernel-trace -d $OUT/pmc_sq -o sq -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > $OUT/pmc_sq.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT --kernel-trace -d $OUT/pmc_sq -o sq -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events --no-train-step > $OUT/pmc_sq.log 2>&1
 echo "sq done"
+rocprofv3 --kernel-trace --stats -d $OUT/stats_wide -o stats -- python3 $ROOT/tools/prof_wide.py 16,256,8,8,3 > $OUT/stats_wide.log 2>&1
+echo "wide done"
 find $OUT -name "*.csv" | head -20

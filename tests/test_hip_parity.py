@@ -554,3 +554,42 @@ def test_wide_weight_gradient_pieces(H, oracle, pad):
     dw = H.dw_from(dev(x), dev(gz), (K, K), order)
     dw_o = oracle.dw(x.astype(np.float64), gz.astype(np.float64), (K, K), 0, order, nthreads=8)
     assert rel_err(host(dw), dw_o) < TOL
+
+
+def test_mailbox_regions_do_not_depend_on_the_channel_count(H):
+    """An image's mailbox region is the same 80 KiB whatever C is, so a granule left by a launch of another channel count
+    can only carry an older tag of the SAME image.  Deterministic: three C = 64 launches of two images, then one C = 32
+    launch of four on one caller-owned block; afterwards the tags found in image b's region are bounded by image b's own
+    generation -- images 2 and 3, new to the block, hold nothing but the tag of their single launch -- and every result
+    equals the whole-image scan bit for bit."""
+    torch.manual_seed(12)
+    L = H.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    own = torch.zeros(L.ifl_scan_state_bytes() + 256, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    off = (-own.data_ptr()) % 256
+
+    def run(B, C):
+        K, Hh, Ww = 3, 32, 32
+        w = torch.nn.init.dirac_(torch.empty(C, C, K, K)) + 0.02 * torch.randn(C, C, K, K)
+        w[:, -1, -1, -1] = 1.0
+        w, x = w.cuda(), torch.randn(B, C, Hh, Ww, device="cuda")
+        nb = L.ifl_workspace_bytes(H.OP_INVERSE, B, C, Hh, Ww, K, K, 0)
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        z = torch.empty_like(x)
+        assert L.ifl_inverse_f32(x.data_ptr(), w.data_ptr(), z.data_ptr(), B, C, Hh, Ww, K, K, 0, 0, ws.data_ptr(), nb, None,
+                                 own.data_ptr() + off, stream) == 0
+        assert torch.equal(z, H.inverse(x, w, "TL", H.FLAG_WHOLE_IMAGE)), (B, C)
+
+    for _ in range(3):
+        run(2, 64)
+    run(4, 32)
+    torch.cuda.synchronize()
+    st = own[off:off + 512 + 4 * 80 * 1024].cpu().numpy()
+    gen = st[:512].view(np.uint32)
+    assert list(gen[:4]) == [8, 8, 2, 2]  # two per launch
+    for b in range(4):
+        tags = st[512 + b * 80 * 1024:512 + (b + 1) * 80 * 1024].view(np.uint32)[1::2]
+        assert tags.max() == gen[b] - 1 and (tags.max() > 0)  # this launch's tag = generation before it + 1
+        if b >= 2:
+            assert set(np.unique(tags)) <= {0, 1}

@@ -48,10 +48,12 @@ template <int C, int KH, int KW> struct DuoCfg {
     static constexpr int RBB = NPL * 256;  // one row block (16 rows x NPL planes x 16 B)
     static constexpr int SLOTB = 2 * RBB;  // one diagonal: row block 0 (rows above the tile: zero or the hand-off) + the tile
     static constexpr int RINGB = 2 * SLOTB;
-    static constexpr int NXS = 2;          // x quads a row keeps staged ([row][quad % NXS][channel][4])
+    static constexpr int QG = 2;           // quads of a row that one x / z duty moves between registers and staging
+    static constexpr int NXS = 2 * QG;     // x quads a row keeps staged ([row][quad % NXS][channel][4])
     static constexpr int XROWB = NXS * C * 16 + 16;
     static constexpr int XSB = 16 * XROWB;
-    static constexpr int ZROWB = 2 * C * 16 + 16; // z quads: [row][quad parity][channel][4]
+    static constexpr int NZS = 2 * QG;     // z quads: [row][quad % NZS][channel][4]
+    static constexpr int ZROWB = NZS * C * 16 + 16;
     static constexpr int ZQB = 16 * ZROWB;
     static constexpr int OFF_XS = RINGB, OFF_ZQ = OFF_XS + XSB, OFF_DUMP = OFF_ZQ + ZQB;
     static constexpr int DUMPB = 4 * 256 + 64 * NW * 8; // where chain lanes outside the image write their r
@@ -79,8 +81,10 @@ template <int C, int KH, int KW> struct DuoCfg {
 };
 
 // Development aid (tools/exp_scan.sh): what-if builds that drop one kind of work (results are then garbage) to see what
-// a step is waiting for.  1: no x loads, 2: no z stores, 4: no z product, 8: no hand-off, 16: no mailbox prefetch.  Never
-// defined in the product.
+// a step is waiting for.  1: no x loads, 2: no z stores, 4: no z product, 8: no hand-off, 16: no mailbox prefetch, 32: no x
+// duty, 64: no z duty, 128: no wait at a row's first use.  Any bit also compiles the redo passes out (the verdict is forced
+// good), which alone is worth 1.8 us: compare what-if builds with each other (a bit without effect, e.g. 8192, is the
+// baseline), not with the product.  Never defined in the product.
 #ifndef IFL_EXP
 #define IFL_EXP 0
 #endif
@@ -613,6 +617,11 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
         static_assert(!PAD, "the duo scan takes layers of exactly 32 or 64 channels (launch_scan_mfma routes the others)");
         constexpr int RPH = 16 / NW, NIM = C / 8, PFR = Cfg::PF, PFX = 2, NQL = 8; // (W = 32: 8 quads per row)
         const int lq = lane & 7, lc = lane >> 3; // this lane's quad of the line and channel within the instruction
+        constexpr int QG = Cfg::QG;
+        static_assert(Cfg::NXS == Cfg::NZS && NQL % QG == 0, "one staging offset per lane serves both duties");
+        constexpr unsigned long long QMASK = 0x0101010101010101ull * ((1u << QG) - 1u); // QG neighbouring lanes of every 8
+        // where this lane's quad goes inside a row's staging: slot = its (logical) quad index modulo the slots
+        const unsigned qs_lane = (unsigned)(((rw ? NQL - 1 - lq : lq) & (Cfg::NXS - 1)) * (C * 16) + lc * 16);
         unsigned go[NIM];                        // byte offset inside an image of what this lane moves in instruction i
 #pragma unroll
         for (int i = 0; i < NIM; ++i) go[i] = (unsigned)((8 * i + lc) * H * W * 4 + lq * 16);
@@ -638,18 +647,22 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
     do {              \
     } while (0)
 #endif
-        // "all but the n youngest vector-memory operations are complete" for a run-time n (an immediate in the instruction)
+        // "all but the n youngest vector-memory operations are complete" for a run-time n (an immediate in the instruction).
+        // The counts that occur are small (see `behind`): a short switch, anything else waits for everything.
         auto wait_vm = [&](int n) {
 #define IFL_V(N) \
     case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-            switch (n < 0 ? 0 : n) {
-                IFL_V(0) IFL_V(1) IFL_V(2) IFL_V(3) IFL_V(4) IFL_V(5) IFL_V(6) IFL_V(7) IFL_V(8) IFL_V(9) IFL_V(10) IFL_V(11)
-                IFL_V(12) IFL_V(13) IFL_V(14) IFL_V(15) IFL_V(16) IFL_V(17) IFL_V(18) IFL_V(19) IFL_V(20) IFL_V(21) IFL_V(22)
-                IFL_V(23) IFL_V(24) IFL_V(25) IFL_V(26) IFL_V(27) IFL_V(28) IFL_V(29) IFL_V(30) IFL_V(31) IFL_V(32) IFL_V(33)
-                IFL_V(34) IFL_V(35) IFL_V(36) IFL_V(37) IFL_V(38) IFL_V(39) IFL_V(40) IFL_V(41) IFL_V(42) IFL_V(43) IFL_V(44)
-                IFL_V(45) IFL_V(46) IFL_V(47) IFL_V(48) IFL_V(49) IFL_V(50) IFL_V(51) IFL_V(52) IFL_V(53) IFL_V(54) IFL_V(55)
-                IFL_V(56)
-            default: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
+            if constexpr (16 / NW == 4) {
+                switch (n) {
+                    IFL_V(1) IFL_V(2) IFL_V(3) IFL_V(4) IFL_V(5) IFL_V(6)
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                }
+            } else {
+                switch (n) {
+                    IFL_V(1) IFL_V(2) IFL_V(3) IFL_V(4) IFL_V(5) IFL_V(6) IFL_V(7) IFL_V(8) IFL_V(9) IFL_V(10) IFL_V(11) IFL_V(12)
+                    IFL_V(13) IFL_V(14) IFL_V(15) IFL_V(16) IFL_V(17) IFL_V(18)
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                }
             }
 #undef IFL_V
         };
@@ -731,15 +744,18 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                     }
                 };
 
-                // vector-memory operations this wave issues behind the loads of its buffer k, up to that row's first use:
-                // the loads of its later rows, and (mailbox helper) one mailbox operation in each of the PFR - PFX steps
+                // What the first use of buffer k (PFR - PFX steps after its loads went out) does NOT wait for: the operations
+                // this wave issued in the last three steps -- one mailbox operation per step of the mailbox helper's
+                // PFR - PFX steps in between, and the loads of its rows k + 4 .. k + 6 (only a wave with eight rows has
+                // such).  Rows k + 1 .. k + 3 went out 5, 4, 3 steps ago: they are waited for too, which costs nothing
+                // (they have landed) and keeps the set of counts small.
                 int behind[RPH];
 #pragma unroll
                 for (int k = 0; k < RPH; ++k) {
                     int n = (mbox ? PFR - PFX : 0);
 #pragma unroll
-                    for (int k2 = k + 1; k2 < RPH; ++k2)
-                        if (k2 - k <= PFR - PFX && RPH * wv + k2 < Hp) n += NIM; // (loaded k2 - k steps later: before the use)
+                    for (int k2 = k + 4; k2 < RPH; ++k2)
+                        if (k2 - k <= PFR - PFX && RPH * wv + k2 < Hp) n += NIM;
                     behind[k] = n;
                 }
                 // A tile that takes no hand-off starts LEAD steps before its first pixel instead of PFR: the rows the
@@ -754,14 +770,11 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                     if (3 < Hp) rb_load_row<3 * 4 * NIM, NIM>(go, xg + row_off(3));
 #pragma unroll
                     for (int k = 0; k < NBURST; ++k) {
-                        // younger than row k's loads at its first use (step k - PFX, after that step's load duty): the burst's
-                        // later rows, the rows the loop has loaded since (r = 4 .. k + PFR - PFX, this wave's if RPH = 8), and
-                        // one mailbox store per finished step
+                        // not waited for at row k's first use (step k - PFX): the rows the loop loaded in the last three steps
+                        // (r = k + 4 .. k + 6, this wave's if it has eight rows) and one mailbox store per finished step
                         int n = 0;
-                        for (int k2 = k + 1; k2 < NBURST; ++k2)
-                            if (k2 < Hp) n += NIM;
                         if (RPH > NBURST)
-                            for (int r = NBURST; r <= k + PFR - PFX && r < RPH; ++r)
+                            for (int r = (k + 4 > NBURST ? k + 4 : NBURST); r <= k + PFR - PFX && r < RPH; ++r)
                                 if (r < Hp) n += NIM;
                         if (publish && mbox) n += k + LEAD - PFX;
                         behind[k] = n;
@@ -821,23 +834,24 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                             }
                         }
                     }
-                    // ---- x duty: quad ql of this wave's row(s) r = d + PFX (mod 4) -> x staging [row][ql & 1][channel][4]
+                    // ---- x duty: the next QG quads of this wave's row(s) r = d + PFX (mod 4) -> x staging [row][quad % NXS][channel][4]
+                    //      (every QG-th time the row is due: the duty's LDS instructions carry 8 QG lanes each)
 #pragma unroll
                     for (int j = 0; j < RPH / 4; ++j) {
                         constexpr int KX0 = (P + PFX) & 3;
                         const int r = RPH * wv + KX0 + 4 * j;
-                        const int ql = (d + PFX - r) >> 2;
-                        if ((unsigned)(d + PFX - r) < (r < Hp ? 4u * NQL : 0u)) { // r < Hp && 0 <= ql < NQL (wave-uniform)
-                            if (ql == 0) wait_vm(behind[KX0 + 4 * j]); // the row has landed (first use)
-                            const int pq = rw ? NQL - 1 - ql : ql;
-                            const unsigned la = ldsbase + Cfg::OFF_XS + r * Cfg::XROWB + (ql & 1) * (C * 16) + lc * 16;
-                            if (j == 0) rb_write_all<4 * KX0 * NIM, NIM>(0x0101010101010101ull << pq, la);
-                            else rb_write_all<4 * ((KX0 + 4) % RPH) * NIM, NIM>(0x0101010101010101ull << pq, la);
+                        const int v = d + PFX - r, ql = v >> 2;
+                        if ((unsigned)v < (r < Hp ? 4u * NQL : 0u) && (ql & (QG - 1)) == 0 && !(IFL_EXP & 32)) { // (wave-uniform)
+                            if (ql == 0 && !(IFL_EXP & 128)) wait_vm(behind[KX0 + 4 * j]); // the row has landed (first use)
+                            const int p0 = rw ? NQL - QG - ql : ql; // lowest lane quad of the group
+                            const unsigned la = ldsbase + Cfg::OFF_XS + r * Cfg::XROWB + qs_lane;
+                            if (j == 0) rb_write_all<4 * KX0 * NIM, NIM>(QMASK << p0, la);
+                            else rb_write_all<4 * ((KX0 + 4) % RPH) * NIM, NIM>(QMASK << p0, la);
                         }
                     }
                     // ---- the mailbox helper issues exactly one vector-memory operation per step besides its rows:
                     //      the line to be delivered PFH steps from now (lower part) ...
-                    if (mb_in && d == -2 - PFH) {
+                    if constexpr (((-2 - PFH) % 4 + 4) % 4 == P) if (mb_in && d == -2 - PFH) {
                         // gate: the first line is requested once the upper part's diagonal 14 + GATE is visible, so that every
                         // later request (one per step, like the upper part's lines) finds its line; the steps before this one
                         // (this tile's first rows are on their way) did not have to wait for the upper part
@@ -909,17 +923,18 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                         asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(lane * 16), "v"(q), "s"(line) : "memory");
                     }
                     // ---- z duty: this wave's row(s) r = d - 5 (mod 4) completed a quad of z with diagonal d-2 (staged one step
-                    //      ago); it joins the registers its x came from, and the row's last quad sends the row out
+                    //      ago); when it is the last of a group of QG they join the registers their x came from, and the row's
+                    //      last group sends the row out
 #pragma unroll
                     for (int j = 0; j < RPH / 4; ++j) {
                         constexpr int KZ0 = (P + 3) & 3; // (d - 5) mod 4
                         const int r = RPH * wv + KZ0 + 4 * j;
-                        const int ql = (d - 5 - r) >> 2;
-                        if ((unsigned)(d - 5 - r) < (r < Hp ? 4u * NQL : 0u)) { // r < Hp && 0 <= ql < NQL (wave-uniform)
-                            const int pq = rw ? NQL - 1 - ql : ql;
-                            const unsigned la = ldsbase + Cfg::OFF_ZQ + r * Cfg::ZROWB + (ql & 1) * (C * 16) + lc * 16;
-                            if (j == 0) rb_read_all<4 * KZ0 * NIM, NIM>(0x0101010101010101ull << pq, la);
-                            else rb_read_all<4 * ((KZ0 + 4) % RPH) * NIM, NIM>(0x0101010101010101ull << pq, la);
+                        const int v = d - 5 - r, ql = v >> 2;
+                        if ((unsigned)v < (r < Hp ? 4u * NQL : 0u) && (ql & (QG - 1)) == QG - 1 && !(IFL_EXP & 64)) { // (wave-uniform)
+                            const int p0 = rw ? NQL - 1 - ql : ql - (QG - 1);
+                            const unsigned la = ldsbase + Cfg::OFF_ZQ + r * Cfg::ZROWB + qs_lane;
+                            if (j == 0) rb_read_all<4 * KZ0 * NIM, NIM>(QMASK << p0, la);
+                            else rb_read_all<4 * ((KZ0 + 4) % RPH) * NIM, NIM>(QMASK << p0, la);
                             if (ql == NQL - 1 && !(IFL_EXP & 2)) {
                                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                                 char *dst = zg + row_off(r);
@@ -932,13 +947,13 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                     //      not live: before a row's first quad, or in the parity its last one does not use)
                     if (zprod) {
                         const int wz = d - 1 - n;
-                        const unsigned za = zadr + ((wz >> 2) & 1) * (C * 16) + (rw ? 3 - (wz & 3) : (wz & 3)) * 4;
+                        const unsigned za = zadr + ((wz >> 2) & (Cfg::NZS - 1)) * (C * 16) + (rw ? 3 - (wz & 3) : (wz & 3)) * 4;
                         float zv[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            zv[r] = (zh[r] + zm[r] * LO_INV) * zscale;
-                            asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(za), "v"(zv[r]), "n"(r * 16) : "memory");
-                        }
+                        for (int r = 0; r < 4; ++r) zv[r] = (zh[r] + zm[r] * LO_INV) * zscale;
+                        asm volatile("ds_write2_b32 %0, %1, %2 offset0:0 offset1:4\n\tds_write2_b32 %0, %3, %4 offset0:8 offset1:12" ::"v"(za),
+                                     "v"(zv[0]), "v"(zv[1]), "v"(zv[2]), "v"(zv[3])
+                                     : "memory");
                         // max |z| from the staged values: a column outside the image repeats an older pixel of its row (the
                         // ring keeps it) or is zero, so the maximum over everything staged is the maximum over the image
                         zmax = fmaxf(fmaxf(zmax, fabsf(zv[0])), fmaxf(fabsf(zv[1]), fmaxf(fabsf(zv[2]), fabsf(zv[3]))));

@@ -12,6 +12,6 @@ done
 wait
 for a in "$@"; do
   e=${a%%:*}
-  objs=$(ls build/*.o | grep -v scan_duo)
+  objs=$(ls build/*.o | grep -v scan_duo | grep -v "build/wide_x")
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o lib/libinvflow_hip_$e.so $objs build/scan_duo_x$e.o && echo lib/libinvflow_hip_$e.so
 done

@@ -654,13 +654,13 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
     case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
             if constexpr (16 / NW == 4) {
                 switch (n) {
-                    IFL_V(1) IFL_V(2) IFL_V(3) IFL_V(4) IFL_V(5) IFL_V(6)
+                    IFL_V(1) IFL_V(2) IFL_V(3) IFL_V(4) IFL_V(5) IFL_V(6) IFL_V(7)
                 default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
                 }
             } else {
                 switch (n) {
                     IFL_V(1) IFL_V(2) IFL_V(3) IFL_V(4) IFL_V(5) IFL_V(6) IFL_V(7) IFL_V(8) IFL_V(9) IFL_V(10) IFL_V(11) IFL_V(12)
-                    IFL_V(13) IFL_V(14) IFL_V(15) IFL_V(16) IFL_V(17) IFL_V(18)
+                    IFL_V(13) IFL_V(14) IFL_V(15) IFL_V(16) IFL_V(17) IFL_V(18) IFL_V(19)
                 default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
                 }
             }
@@ -746,13 +746,13 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
 
                 // What the first use of buffer k (PFR - PFX steps after its loads went out) does NOT wait for: the operations
                 // this wave issued in the last three steps -- one mailbox operation per step of the mailbox helper's
-                // PFR - PFX steps in between, and the loads of its rows k + 4 .. k + 6 (only a wave with eight rows has
+                // PFR - PFX steps in between and of the step itself, and the loads of its rows k + 4 .. k + 6 (only a wave with eight rows has
                 // such).  Rows k + 1 .. k + 3 went out 5, 4, 3 steps ago: they are waited for too, which costs nothing
                 // (they have landed) and keeps the set of counts small.
                 int behind[RPH];
 #pragma unroll
                 for (int k = 0; k < RPH; ++k) {
-                    int n = (mbox ? PFR - PFX : 0);
+                    int n = (mbox ? PFR - PFX + 1 : 0); // (the x duty comes behind its own step's mailbox operation)
 #pragma unroll
                     for (int k2 = k + 4; k2 < RPH; ++k2)
                         if (k2 - k <= PFR - PFX && RPH * wv + k2 < Hp) n += NIM;
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                         if (RPH > NBURST)
                             for (int r = (k + 4 > NBURST ? k + 4 : NBURST); r <= k + PFR - PFX && r < RPH; ++r)
                                 if (r < Hp) n += NIM;
-                        if (publish && mbox) n += k + LEAD - PFX;
+                        if (publish && mbox) n += k + LEAD - PFX + 1;
                         behind[k] = n;
                     }
                 }
@@ -832,21 +832,6 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                                 if ((r >> 2) & 1) rb_load_row<4 * (P + 4) * NIM, NIM>(go, src);
                                 else rb_load_row<4 * P * NIM, NIM>(go, src);
                             }
-                        }
-                    }
-                    // ---- x duty: the next QG quads of this wave's row(s) r = d + PFX (mod 4) -> x staging [row][quad % NXS][channel][4]
-                    //      (every QG-th time the row is due: the duty's LDS instructions carry 8 QG lanes each)
-#pragma unroll
-                    for (int j = 0; j < RPH / 4; ++j) {
-                        constexpr int KX0 = (P + PFX) & 3;
-                        const int r = RPH * wv + KX0 + 4 * j;
-                        const int v = d + PFX - r, ql = v >> 2;
-                        if ((unsigned)v < (r < Hp ? 4u * NQL : 0u) && (ql & (QG - 1)) == 0 && !(IFL_EXP & 32)) { // (wave-uniform)
-                            if (ql == 0 && !(IFL_EXP & 128)) wait_vm(behind[KX0 + 4 * j]); // the row has landed (first use)
-                            const int p0 = rw ? NQL - QG - ql : ql; // lowest lane quad of the group
-                            const unsigned la = ldsbase + Cfg::OFF_XS + r * Cfg::XROWB + qs_lane;
-                            if (j == 0) rb_write_all<4 * KX0 * NIM, NIM>(QMASK << p0, la);
-                            else rb_write_all<4 * ((KX0 + 4) % RPH) * NIM, NIM>(QMASK << p0, la);
                         }
                     }
                     // ---- the mailbox helper issues exactly one vector-memory operation per step besides its rows:
@@ -922,6 +907,38 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                         char *line = mb + (size_t)(h_out ? u : DUO_LINES - 2) * DUO_LINEB;
                         asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(lane * 16), "v"(q), "s"(line) : "memory");
                     }
+                    // ---- x duty: the next QG quads of this wave's row(s) r = d + PFX (mod 4) -> x staging [row][quad % NXS][channel][4]
+                    //      (every QG-th time the row is due: the duty's LDS instructions carry 8 QG lanes each).  Here, behind the z
+                    //      product, and not at the head of the step: in front of the wait for the r fragments its eight writes
+                    //      delayed the z product, and with it the barrier, in almost every step (some helper has a row due).
+#pragma unroll
+                    for (int j = 0; j < RPH / 4; ++j) {
+                        constexpr int KX0 = (P + PFX) & 3;
+                        const int r = RPH * wv + KX0 + 4 * j;
+                        const int v = d + PFX - r, ql = v >> 2;
+                        if ((unsigned)v < (r < Hp ? 4u * NQL : 0u) && (ql & (QG - 1)) == 0 && !(IFL_EXP & 32)) { // (wave-uniform)
+                            if (ql == 0 && !(IFL_EXP & 128)) wait_vm(behind[KX0 + 4 * j]); // the row has landed (first use)
+                            const int p0 = rw ? NQL - QG - ql : ql; // lowest lane quad of the group
+                            const unsigned la = ldsbase + Cfg::OFF_XS + r * Cfg::XROWB + qs_lane;
+                            if (j == 0) rb_write_all<4 * KX0 * NIM, NIM>(QMASK << p0, la);
+                            else rb_write_all<4 * ((KX0 + 4) % RPH) * NIM, NIM>(QMASK << p0, la);
+                        }
+                    }
+                    // ---- z -> staging, at that column's in-row offset (columns outside the image land in quads that are
+                    //      not live: before a row's first quad, or in the parity its last one does not use)
+                    if (zprod) {
+                        const int wz = d - 1 - n;
+                        const unsigned za = zadr + ((wz >> 2) & (Cfg::NZS - 1)) * (C * 16) + (rw ? 3 - (wz & 3) : (wz & 3)) * 4;
+                        float zv[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) zv[r] = (zh[r] + zm[r] * LO_INV) * zscale;
+                        asm volatile("ds_write2_b32 %0, %1, %2 offset0:0 offset1:4\n\tds_write2_b32 %0, %3, %4 offset0:8 offset1:12" ::"v"(za),
+                                     "v"(zv[0]), "v"(zv[1]), "v"(zv[2]), "v"(zv[3])
+                                     : "memory");
+                        // max |z| from the staged values: a column outside the image repeats an older pixel of its row (the
+                        // ring keeps it) or is zero, so the maximum over everything staged is the maximum over the image
+                        zmax = fmaxf(fmaxf(zmax, fabsf(zv[0])), fmaxf(fabsf(zv[1]), fmaxf(fabsf(zv[2]), fabsf(zv[3]))));
+                    }
                     // ---- z duty: this wave's row(s) r = d - 5 (mod 4) completed a quad of z with diagonal d-2 (staged one step
                     //      ago); when it is the last of a group of QG they join the registers their x came from, and the row's
                     //      last group sends the row out
@@ -943,23 +960,10 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                             }
                         }
                     }
-                    // ---- z -> staging, at that column's in-row offset (columns outside the image land in quads that are
-                    //      not live: before a row's first quad, or in the parity its last one does not use)
-                    if (zprod) {
-                        const int wz = d - 1 - n;
-                        const unsigned za = zadr + ((wz >> 2) & (Cfg::NZS - 1)) * (C * 16) + (rw ? 3 - (wz & 3) : (wz & 3)) * 4;
-                        float zv[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) zv[r] = (zh[r] + zm[r] * LO_INV) * zscale;
-                        asm volatile("ds_write2_b32 %0, %1, %2 offset0:0 offset1:4\n\tds_write2_b32 %0, %3, %4 offset0:8 offset1:12" ::"v"(za),
-                                     "v"(zv[0]), "v"(zv[1]), "v"(zv[2]), "v"(zv[3])
-                                     : "memory");
-                        // max |z| from the staged values: a column outside the image repeats an older pixel of its row (the
-                        // ring keeps it) or is zero, so the maximum over everything staged is the maximum over the image
-                        zmax = fmaxf(fmaxf(zmax, fabsf(zv[0])), fmaxf(fabsf(zv[1]), fmaxf(fabsf(zv[2]), fabsf(zv[3]))));
-                    }
                     IFL_HSTAMP(5); // z quad + staging
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // x quads and z staged by this wave are in LDS
+                    // (everything this wave put into the LDS is done before the barrier: operations left in flight across it --
+                    // tried -- sit in the LDS queue in front of the chain waves' fragment reads of the next step: +4 us)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 };
                 static_assert(PFR % 4 == 0, "the sweep starts at a step that is 0 modulo 4");
                 for (int d = dfirst; d <= ND + 1; d += 4) {

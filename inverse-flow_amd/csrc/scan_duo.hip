@@ -66,7 +66,7 @@ template <int C, int KH, int KW> struct DuoCfg {
     static constexpr int PF = 8;           // x quads are requested PF steps before their first use
     static constexpr int LEAD = 4;         // steps before the first pixel of a tile that takes no hand-off (its first rows: one burst)
 #ifndef IFL_PFH
-#define IFL_PFH 3
+#define IFL_PFH 2
 #endif
     static constexpr int PFH = IFL_PFH;    // mailbox lines are requested PFH steps before they are delivered
 #ifndef IFL_A_VS
@@ -807,19 +807,6 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PFH - 1) : "memory");
                         lds_read_f32x4(hq, ldsbase + Cfg::OFF_HALO + (d & (Cfg::NHL - 1)) * 1024 + lane * 16);
                     }
-                    half8 Fh[NQ], Fl[NQ];
-                    if (zprod) {
-                        const unsigned fa = fadr + ((d + 1) & 1) * SLOTB;
-                        lds_read_b128_o<0>(Fh[0], fa);
-                        lds_read_b128_o<4 * 256>(Fl[0], fa);
-                        if constexpr (NQ == 2) {
-                            lds_read_b128_o<8 * 256>(Fh[1], fa);
-                            lds_read_b128_o<12 * 256>(Fl[1], fa);
-                        }
-                    }
-                    uintx2 pv;
-                    if (h_out)
-                        asm volatile("ds_read_b64 %0, %1" : "=v"(pv) : "v"(madr + RBB + ((d - 1) & 1) * SLOTB) : "memory");
                     IFL_HSTAMP(1); // requests
                     // ---- load duty: the row whose first pixel is PFR steps away (this wave's rows come up in consecutive steps)
                     {
@@ -860,6 +847,21 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                                      "global_load_lds_dwordx4 %1, %2 sc0 sc1" ::"s"(dst), "v"(lane * 16), "s"(line)
                                      : "memory", "m0");
                     }
+                    // (this wave's own LDS requests go out behind its memory instructions: the chain waves' fragment reads,
+                    // issued right after the barrier, are ahead of them in the LDS queue)
+                    half8 Fh[NQ], Fl[NQ];
+                    if (zprod) {
+                        const unsigned fa = fadr + ((d + 1) & 1) * SLOTB;
+                        lds_read_b128_o<0>(Fh[0], fa);
+                        lds_read_b128_o<4 * 256>(Fl[0], fa);
+                        if constexpr (NQ == 2) {
+                            lds_read_b128_o<8 * 256>(Fh[1], fa);
+                            lds_read_b128_o<12 * 256>(Fl[1], fa);
+                        }
+                    }
+                    uintx2 pv;
+                    if (h_out)
+                        asm volatile("ds_read_b64 %0, %1" : "=v"(pv) : "v"(madr + RBB + ((d - 1) & 1) * SLOTB) : "memory");
                     IFL_HSTAMP(2); // row load + x quad
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     IFL_HSTAMP(3); // LDS wait

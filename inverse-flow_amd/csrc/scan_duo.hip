@@ -977,7 +977,9 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                     if (d + 3 > ND + 1) break;
                     step(std::integral_constant<int, 3>{}, d + 3);
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // (the last rows' stores and the last mailbox operations are still on their way.  A redo pass reuses the
+                // row registers and waits for them; the launched tile's sweep lets the wave run on to the verdict)
+                if (pass > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             // ================================ between the sweeps ========================================================
             if (pass > 0) {
@@ -1028,6 +1030,7 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                 return;
             }
             // redo: scaled sweeps of both tiles through the mailbox, under the second tag
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             zmax = 0.f;
             dead = 0;
         }

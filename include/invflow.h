@@ -246,6 +246,18 @@ int ifl_rqspline_backward_f32(const float *gy, const float *g_logdet, const floa
                               const float *dv, int n_bins, float tail_bound, float *gx, float *g_tables, int B, int C, int H,
                               int W, void *ws, size_t ws_bytes, ifl_stream_t stream);
 
+/* SplineActivation with INDIVIDUAL weights (activations.py:135-144: one set of knots per element; parameters of shape
+ * (1, C, H, W, n_bins) -- here P = C*H*W element positions, DEVICE arrays uw, uh of P*n_bins floats and ud of P*(n_bins-1)).
+ * x, y: (B, P).  The knot tables are built inside the kernels.  inverse / logdet as for ifl_rqspline_f32.
+ * Backward of the forward direction: gx (B, P) and g_params = [g_uw (P*n_bins) | g_uh (P*n_bins) | g_ud (P*(n_bins-1))],
+ * summed over the batch in a fixed order.  ws: ifl_rqspline_pe_workspace_bytes. */
+size_t ifl_rqspline_pe_workspace_bytes(int B, int P, int n_bins);
+int ifl_rqspline_pe_f32(const float *x, const float *uw, const float *uh, const float *ud, int n_bins, float tail_bound, float *y,
+                        float *logdet, int B, int P, int inverse, void *ws, size_t ws_bytes, ifl_stream_t stream);
+int ifl_rqspline_pe_backward_f32(const float *gy, const float *g_logdet, const float *x, const float *uw, const float *uh,
+                                 const float *ud, int n_bins, float tail_bound, float *gx, float *g_params, int B, int P, void *ws,
+                                 size_t ws_bytes, ifl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

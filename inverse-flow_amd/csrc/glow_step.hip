@@ -782,6 +782,182 @@ __global__ void k_rq_tables_bwd(const float *__restrict__ gt, const float *__res
     for (int j = 1; j < K; ++j) gud[j - 1] = gd[j] / (1.0f + expf(-(ud[j - 1] + c)));
 }
 
+
+// ---- the spline with one set of knots per element ("individual weights", activations.py:135-144: parameters of shape
+// (1, C, H, W, n_bins): the MNIST Glow's activation).  A thread owns one element position e of the P = C H W and a group of
+// images: it builds that element's knot tables in registers (the formulas of k_rq_tables), walks its images, and -- backward
+// -- turns the sums of the table gradients into parameter gradients itself (k_rq_tables_bwd's formulas): the three
+// parameter tensors are read once per thread and their gradients leave as one partial per image group, summed in a fixed
+// order afterwards.  The reference's torch expressions expand three (B, C, H, W, n_bins + 1) tensors and gather along the
+// bin axis: ~40 launches forward, ~80 backward.
+template <int NB> __device__ __forceinline__ void rq_tables_of(const float *uw, const float *uh, const float *ud, float T, RqTables &t,
+                                                               float (&pw)[NB], float (&ph)[NB])
+{
+    const float m = 1e-6f, c = logf(expf(1.0f - m) - 1.0f);
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const float *u = which ? uh : uw;
+        float mx = u[0];
+#pragma unroll
+        for (int i = 1; i < NB; ++i) mx = fmaxf(mx, u[i]);
+        float ex[NB], den = 0.f;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            ex[i] = expf(u[i] - mx);
+            den += ex[i];
+        }
+        float cum = 0.f;
+        float *out = which ? t.ch : t.cw;
+        out[0] = -T;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const float pi = ex[i] / den;
+            (which ? ph : pw)[i] = pi; // softmax, kept for the way back
+            cum += m + (1.0f - m * NB) * pi;
+            out[i + 1] = i + 1 == NB ? T : 2.0f * T * cum - T;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j <= NB; ++j) {
+        const float a = (j == 0 || j == NB) ? c : ud[j - 1] + c;
+        t.dv[j] = m + (fmaxf(a, 0.f) + log1pf(expf(-fabsf(a))));
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(64) void k_rqspline_pe(const float *__restrict__ x, const float *__restrict__ uw,
+                                                    const float *__restrict__ uh, const float *__restrict__ ud,
+                                                    float *__restrict__ y, float *__restrict__ lpart, int B, int P, int BG,
+                                                    float tail, int inverse)
+{
+    const int e = blockIdx.x * 64 + threadIdx.x, b0 = blockIdx.y * BG, b1 = b0 + BG < B ? b0 + BG : B;
+    const bool ok = e < P;
+    const int ec = ok ? e : P - 1;
+    float pu[NB], ph_[NB], pd[NB > 1 ? NB - 1 : 1];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        pu[j] = uw[(size_t)ec * NB + j];
+        ph_[j] = uh[(size_t)ec * NB + j];
+    }
+#pragma unroll
+    for (int j = 0; j + 1 < NB; ++j) pd[j] = ud[(size_t)ec * (NB - 1) + j];
+    RqTables t;
+    float sw[NB], sh_[NB];
+    rq_tables_of<NB>(pu, ph_, pd, tail, t, sw, sh_);
+    for (int b = b0; b < b1; ++b) {
+        float lad = 0.f;
+        if (ok) {
+            const float v = x[(size_t)b * P + e];
+            float out = v;
+            if (v >= -tail && v <= tail) {
+                float a, bb, c, ee, d0, d1;
+                if (!inverse) {
+                    rq_pick<NB>(t, rq_bin<NB>(t.cw, v), a, bb, c, ee, d0, d1);
+                    rq_eval<float>(v, a, bb, c, ee, d0, d1, out, lad, flog);
+                } else {
+                    rq_pick<NB>(t, rq_bin<NB>(t.ch, v), a, bb, c, ee, d0, d1);
+                    const float w = bb - a, h = ee - c, delta = h / w, s = d0 + d1 - 2.f * delta, r = v - c;
+                    const float qa = r * s + h * (delta - d0), qb = h * d0 - r * s, qc = -delta * r;
+                    const float root = (2.f * qc) / (-qb - sqrtf(qb * qb - 4.f * qa * qc));
+                    out = root * w + a;
+                    const float t1 = root * (1.f - root), den = delta + s * t1;
+                    const float dnum = delta * delta * (d1 * root * root + 2.f * delta * t1 + d0 * (1.f - root) * (1.f - root));
+                    lad = -(__logf(dnum) - 2.f * __logf(den));
+                }
+            }
+            y[(size_t)b * P + e] = out;
+        }
+        if (lpart) {
+            for (int o = 32; o > 0; o >>= 1) lad += __shfl_down(lad, o, 64);
+            if (threadIdx.x == 0) lpart[(size_t)b * gridDim.x + blockIdx.x] = lad;
+        }
+    }
+}
+
+// gpart[group][uw: P NB | uh: P NB | ud: P (NB - 1)]
+template <int NB>
+__global__ __launch_bounds__(64) void k_rqspline_pe_bwd(const float *__restrict__ gy, const float *__restrict__ g_logdet,
+                                                        const float *__restrict__ x, const float *__restrict__ uw,
+                                                        const float *__restrict__ uh, const float *__restrict__ ud,
+                                                        float *__restrict__ gx, float *__restrict__ gpart, int B, int P, int BG,
+                                                        float tail)
+{
+    typedef Dual<7> D;
+    const int e = blockIdx.x * 64 + threadIdx.x, b0 = blockIdx.y * BG, b1 = b0 + BG < B ? b0 + BG : B;
+    if (e >= P) return;
+    float pu[NB], ph_[NB], pd[NB > 1 ? NB - 1 : 1];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        pu[j] = uw[(size_t)e * NB + j];
+        ph_[j] = uh[(size_t)e * NB + j];
+    }
+#pragma unroll
+    for (int j = 0; j + 1 < NB; ++j) pd[j] = ud[(size_t)e * (NB - 1) + j];
+    RqTables t;
+    float sw[NB], sh_[NB];
+    rq_tables_of<NB>(pu, ph_, pd, tail, t, sw, sh_);
+    float gcw[NB + 1], gch[NB + 1], gdv[NB + 1];
+#pragma unroll
+    for (int j = 0; j <= NB; ++j) gcw[j] = gch[j] = gdv[j] = 0.f;
+    for (int b = b0; b < b1; ++b) {
+        const float v = x[(size_t)b * P + e], g = gy[(size_t)b * P + e], gl = g_logdet ? g_logdet[b] : 0.f;
+        float gxi = g;
+        if (v >= -tail && v <= tail) {
+            const int k = rq_bin<NB>(t.cw, v);
+            float a, bb, c, ee, d0, d1;
+            rq_pick<NB>(t, k, a, bb, c, ee, d0, d1);
+            D yy, ll;
+            rq_eval<D>(dvar<7>(v, 0), dvar<7>(a, 1), dvar<7>(bb, 2), dvar<7>(c, 3), dvar<7>(ee, 4), dvar<7>(d0, 5), dvar<7>(d1, 6), yy, ll,
+                       dlog<7>);
+            float q[7];
+#pragma unroll
+            for (int m = 0; m < 7; ++m) q[m] = g * yy.d[m] + gl * ll.d[m];
+            gxi = q[0];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const float on = j == k ? 1.f : 0.f;
+                gcw[j] += on * q[1];
+                gcw[j + 1] += on * q[2];
+                gch[j] += on * q[3];
+                gch[j + 1] += on * q[4];
+                gdv[j] += on * q[5];
+                gdv[j + 1] += on * q[6];
+            }
+        }
+        gx[(size_t)b * P + e] = gxi;
+    }
+    // tables -> parameters (k_rq_tables_bwd): knot j of a cumulative table is fed by the softmax entries 0 .. j - 1
+    const float m = 1e-6f, c0 = logf(expf(1.0f - m) - 1.0f);
+    float *gp = gpart + (size_t)blockIdx.y * P * (3 * NB - 1);
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const float *gk = which ? gch : gcw;
+        const float *pi = which ? sh_ : sw;
+        float gv[NB], tailsum = 0.f, dot = 0.f;
+#pragma unroll
+        for (int i = NB - 1; i >= 0; --i) {
+            gv[i] = (1.0f - m * NB) * 2.0f * tail * tailsum;
+            if (i >= 1) tailsum += gk[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) dot += pi[i] * gv[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) gp[(size_t)which * P * NB + (size_t)e * NB + i] = pi[i] * (gv[i] - dot);
+    }
+#pragma unroll
+    for (int j = 1; j < NB; ++j) gp[(size_t)2 * P * NB + (size_t)e * (NB - 1) + j - 1] = gdv[j] / (1.0f + expf(-(pd[j - 1] + c0)));
+}
+// out[i] = sum over groups of part[g][i], in group order
+__global__ __launch_bounds__(256) void k_group_sums(const float *__restrict__ part, float *__restrict__ out, int G, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += part[(size_t)g * n + i];
+    out[i] = s;
+}
+static int rq_pe_groups(int B) { return B < 4 ? 1 : (B + 3) / 4; } // four images per thread
+
 static int rq_check(const char *who, const float *cw, const float *ch, const float *dv, int nb)
 {
     if (nb < 1 || nb > RQ_MAXB) IFL_FAIL(IFL_EUNSUPPORTED, "%s: n_bins=%d (1..%d supported)", who, nb, RQ_MAXB);
@@ -903,6 +1079,70 @@ int ifl_rqspline_backward_f32(const float *gy, const float *g_logdet, const floa
 #undef IFL_RQ
     }
     hipLaunchKernelGGL(k_table_sums, dim3(3 * (n_bins + 1)), dim3(64), 0, s, tpart, g_tables, planes, 3 * (n_bins + 1));
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+
+size_t ifl_rqspline_pe_workspace_bytes(int B, int P, int n_bins)
+{
+    if (B < 0 || P < 1 || n_bins < 1) return 0;
+    const size_t eb = ((size_t)P + 63) / 64;
+    return (size_t)B * eb * sizeof(float) + (size_t)rq_pe_groups(B) * P * (3 * (size_t)n_bins - 1) * sizeof(float) + 512;
+}
+
+int ifl_rqspline_pe_f32(const float *x, const float *uw, const float *uh, const float *ud, int n_bins, float tail_bound, float *y,
+                        float *logdet, int B, int P, int inverse, void *ws, size_t ws_bytes, ifl_stream_t stream)
+{
+    clear_error();
+    if (B < 0 || P < 1) IFL_FAIL(IFL_EINVAL, "ifl_rqspline_pe_f32: bad shape B=%d P=%d", B, P);
+    if (n_bins < 1 || n_bins > RQ_MAXB) IFL_FAIL(IFL_EUNSUPPORTED, "ifl_rqspline_pe_f32: n_bins=%d (1..%d supported)", n_bins, RQ_MAXB);
+    if (B == 0) return IFL_OK;
+    if (!x || !y || !uw || !uh || (!ud && n_bins > 1)) IFL_FAIL(IFL_EINVAL, "ifl_rqspline_pe_f32: null pointer");
+    if (logdet && (!ws || ws_bytes < ifl_rqspline_pe_workspace_bytes(B, P, n_bins)))
+        IFL_FAIL(IFL_EWORKSPACE, "ifl_rqspline_pe_f32: workspace of %zu bytes needed", ifl_rqspline_pe_workspace_bytes(B, P, n_bins));
+    hipStream_t s = (hipStream_t)stream;
+    const int eb = (P + 63) / 64, G = rq_pe_groups(B), BG = (B + G - 1) / G;
+    float *lpart = logdet ? (float *)(((uintptr_t)ws + 255) & ~(uintptr_t)255) : nullptr;
+    const dim3 grid(eb, G);
+    switch (n_bins) {
+#define IFL_RQ(NB) \
+    case NB: hipLaunchKernelGGL(k_rqspline_pe<NB>, grid, dim3(64), 0, s, x, uw, uh, ud, y, lpart, B, P, BG, tail_bound, inverse); break;
+        IFL_RQ(1) IFL_RQ(2) IFL_RQ(3) IFL_RQ(4) IFL_RQ(5) IFL_RQ(6) IFL_RQ(7) IFL_RQ(8)
+#undef IFL_RQ
+    }
+    if (logdet) hipLaunchKernelGGL(k_plane_sums, dim3((B + 63) / 64), dim3(64), 0, s, lpart, logdet, B, eb);
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+
+int ifl_rqspline_pe_backward_f32(const float *gy, const float *g_logdet, const float *x, const float *uw, const float *uh,
+                                 const float *ud, int n_bins, float tail_bound, float *gx, float *g_params, int B, int P, void *ws,
+                                 size_t ws_bytes, ifl_stream_t stream)
+{
+    clear_error();
+    if (B < 0 || P < 1) IFL_FAIL(IFL_EINVAL, "ifl_rqspline_pe_backward_f32: bad shape B=%d P=%d", B, P);
+    if (n_bins < 1 || n_bins > RQ_MAXB)
+        IFL_FAIL(IFL_EUNSUPPORTED, "ifl_rqspline_pe_backward_f32: n_bins=%d (1..%d supported)", n_bins, RQ_MAXB);
+    if (!g_params) IFL_FAIL(IFL_EINVAL, "ifl_rqspline_pe_backward_f32: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)P * (3 * (size_t)n_bins - 1);
+    if (B == 0) {
+        IFL_HIP(hipMemsetAsync(g_params, 0, n * sizeof(float), s));
+        return IFL_OK;
+    }
+    if (!gy || !x || !gx || !uw || !uh || (!ud && n_bins > 1)) IFL_FAIL(IFL_EINVAL, "ifl_rqspline_pe_backward_f32: null pointer");
+    if (!ws || ws_bytes < ifl_rqspline_pe_workspace_bytes(B, P, n_bins))
+        IFL_FAIL(IFL_EWORKSPACE, "ifl_rqspline_pe_backward_f32: workspace of %zu bytes needed", ifl_rqspline_pe_workspace_bytes(B, P, n_bins));
+    const int eb = (P + 63) / 64, G = rq_pe_groups(B), BG = (B + G - 1) / G;
+    float *gpart = (float *)((((uintptr_t)ws + 255) & ~(uintptr_t)255) + (((size_t)B * eb * sizeof(float) + 255) & ~(size_t)255));
+    const dim3 grid(eb, G);
+    switch (n_bins) {
+#define IFL_RQ(NB) \
+    case NB: hipLaunchKernelGGL(k_rqspline_pe_bwd<NB>, grid, dim3(64), 0, s, gy, g_logdet, x, uw, uh, ud, gx, gpart, B, P, BG, tail_bound); break;
+        IFL_RQ(1) IFL_RQ(2) IFL_RQ(3) IFL_RQ(4) IFL_RQ(5) IFL_RQ(6) IFL_RQ(7) IFL_RQ(8)
+#undef IFL_RQ
+    }
+    hipLaunchKernelGGL(k_group_sums, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gpart, g_params, G, n);
     IFL_HIP(hipGetLastError());
     return IFL_OK;
 }

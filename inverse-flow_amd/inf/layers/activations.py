@@ -8,7 +8,8 @@ SmoothLeakyRelu and SplineActivation (shared weights) run 4-D CUDA inputs throug
     (B, C, H, W, n_bins) tensors and runs splines/rational_quadratic.py on them; here the knot tables (n_bins + 1
     entries each) are computed from the parameters by the same formulas on tiny tensors -- autograd sees that part --
     and the per-element spline with its derivative sums is one kernel each way (ifl_rqspline_f32 / _backward_f32).
-Anything else (other dimensionalities, CPU tensors, individual weights) takes the reference's torch expressions.
+Individual weights (one set of knots per element, the MNIST Glow): ifl_rqspline_pe_f32 / _backward_f32 build the tables in
+registers.  Anything else (other dimensionalities, CPU tensors) takes the reference's torch expressions.
 """
 import os
 
@@ -167,6 +168,28 @@ class _SplineFn(torch.autograd.Function):
         return gx, gcw, gch, gdv, None
 
 
+class _SplinePEFn(torch.autograd.Function):
+    """the spline with per-element knots: one kernel forward (tables built in registers), one backward + a fixed-order sum
+    of the parameter gradients over image groups (ifl_rqspline_pe_f32 / _backward_f32)"""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, x, uw, uh, ud, tail_bound):
+        x, uw, uh, ud = x.contiguous(), uw.contiguous(), uh.contiguous(), ud.contiguous()
+        y, ld = H.rqspline_pe(x, uw, uh, ud, tail_bound)
+        ctx.save_for_backward(x, uw, uh, ud)
+        ctx.tail_bound = tail_bound
+        return y, ld
+
+    @staticmethod
+    @_bwd32
+    def backward(ctx, gy, gld):
+        x, uw, uh, ud = ctx.saved_tensors
+        gx, guw, guh, gud = H.rqspline_pe_backward(gy.contiguous(), gld.contiguous() if gld is not None else None, x, uw, uh, ud,
+                                                   ctx.tail_bound)
+        return gx, guw, guh, gud, None
+
+
 class SplineActivation(FlowActivationLayer):
     def __init__(self, input_size, n_bins=5, tail_bound=10., individual_weights=False):
         super().__init__()
@@ -197,13 +220,23 @@ class SplineActivation(FlowActivationLayer):
     def forward(self, input, context=None):
         return self.activation_and_logdet(input, context)
 
+    def _hip_pe(self, input):
+        return (_hip_ok(input) and self.individual_weights and 1 <= self.n_bins <= 8
+                and tuple(input.shape[1:]) == tuple(self.unnormalized_widths.shape[1:-1]))
+
     def activation_and_logdet(self, input, context=None):
+        if self._hip_pe(input):
+            return _SplinePEFn.apply(input, self.unnormalized_widths, self.unnormalized_heights, self.unnormalized_derivatives,
+                                     float(self.tail_bound))
         if self._hip(input):
             cw, ch, dv = self._tables()
             return _SplineFn.apply(input, cw, ch, dv, float(self.tail_bound))
         return _spline_torch(self, input, inverse=False)
 
     def reverse(self, input, context=None):
+        if self._hip_pe(input) and input.dtype == torch.float32 and not torch.is_grad_enabled():
+            return H.rqspline_pe(input.contiguous(), self.unnormalized_widths.contiguous(), self.unnormalized_heights.contiguous(),
+                                 self.unnormalized_derivatives.contiguous(), float(self.tail_bound), inverse=True, want_logdet=False)[0]
         if self._hip(input) and input.dtype == torch.float32 and not torch.is_grad_enabled():
             cw, ch, dv = self._tables()
             return H.rqspline(input.contiguous(), cw, ch, dv, float(self.tail_bound), inverse=True, want_logdet=False)[0]

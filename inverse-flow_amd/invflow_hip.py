@@ -59,6 +59,9 @@ SIGNATURES = {
     "ifl_rqspline_tables_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     "ifl_rqspline_f32": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ifl_rqspline_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "ifl_rqspline_pe_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ifl_rqspline_pe_f32": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "ifl_rqspline_pe_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _i, _vp, _sz, _vp]),
 }
 
 
@@ -635,6 +638,48 @@ def rqspline_backward(gy, g_logdet, x, cw, ch, dv, tail_bound):
     _check(rc, "ifl_rqspline_backward_f32")
     gt = gt.view(3, nbins + 1)
     return gx, gt[0], gt[1], gt[2]
+
+
+def _pe_params(x, uw, uh, ud):
+    """(B, P, n_bins) of a per-element spline call: x (B, ...), parameters (1, ..., n_bins) / (1, ..., n_bins - 1)"""
+    for t, name in ((x, "input"), (uw, "unnormalized_widths"), (uh, "unnormalized_heights"), (ud, "unnormalized_derivatives")):
+        _chk_tensor(t, name)
+    B, P, nbins = x.shape[0], x[0].numel() if x.shape[0] else int(uw.numel() // uw.shape[-1]), uw.shape[-1]
+    if uw.numel() != P * nbins or uh.numel() != P * nbins or ud.numel() != P * (nbins - 1):
+        raise RuntimeError("per-element spline: parameter shapes do not match the input's element count")
+    return B, P, nbins
+
+
+def rqspline_pe(x, uw, uh, ud, tail_bound, inverse=False, want_logdet=True):
+    """The spline with one set of knots per element (SplineActivation(individual_weights=True), activations.py:135-144):
+    (y, logdet) of the forward or of the inverse map; the knot tables are built inside the kernel."""
+    B, P, nbins = _pe_params(x, uw, uh, ud)
+    dev = _same_device(x, uw, uh, ud)
+    y = torch.empty_like(x)
+    ld = torch.empty(B, dtype=torch.float32, device=dev) if want_logdet else None
+    with _on(dev):
+        nb = int(lib().ifl_rqspline_pe_workspace_bytes(B, P, nbins))
+        ws = _ws(nb, dev)
+        rc = lib().ifl_rqspline_pe_f32(_ptr(x), _ptr(uw), _ptr(uh), _ptr(ud), nbins, float(tail_bound), _ptr(y), _ptr(ld), B, P,
+                                       1 if inverse else 0, _ptr(ws), nb, _stream())
+    _check(rc, "ifl_rqspline_pe_f32")
+    return y, ld
+
+
+def rqspline_pe_backward(gy, g_logdet, x, uw, uh, ud, tail_bound):
+    """(gx, g_uw, g_uh, g_ud) of the forward direction, the parameter gradients summed over the batch."""
+    B, P, nbins = _pe_params(x, uw, uh, ud)
+    _chk_tensor(gy, "grad_output")
+    dev = _same_device(x, gy, uw, uh, ud)
+    gx = torch.empty_like(x)
+    gp = torch.empty(P * (3 * nbins - 1), dtype=torch.float32, device=dev)
+    with _on(dev):
+        nb = int(lib().ifl_rqspline_pe_workspace_bytes(B, P, nbins))
+        ws = _ws(nb, dev)
+        rc = lib().ifl_rqspline_pe_backward_f32(_ptr(gy), _ptr(g_logdet), _ptr(x), _ptr(uw), _ptr(uh), _ptr(ud), nbins,
+                                                float(tail_bound), _ptr(gx), _ptr(gp), B, P, _ptr(ws), nb, _stream())
+    _check(rc, "ifl_rqspline_pe_backward_f32")
+    return (gx, gp[:P * nbins].view(uw.shape), gp[P * nbins:2 * P * nbins].view(uh.shape), gp[2 * P * nbins:].view(ud.shape))
 
 
 def rqspline_tables(uw, uh, ud, tail_bound):

@@ -371,6 +371,20 @@ def spline_tables(uw, uh, ud, tail_bound, min_size=1e-6):
     return knots(uw), knots(uh), min_size + np.logaddexp(0.0, udp)
 
 
+def rqspline_individual(x, uw, uh, ud, tail_bound, inverse=False):
+    """The spline with one set of knots per element (SplineActivation(individual_weights=True), activations.py:135-144):
+    parameters of shape (1, C, H, W, n_bins[-1]); element by element with the shared-weight functions above.
+    Returns (y, logabsdet) like rqspline."""
+    x = np.asarray(x, np.float64)
+    uw, uh, ud = (np.asarray(a, np.float64).reshape(-1, np.shape(a)[-1]) for a in (uw, uh, ud))
+    xf = x.reshape(x.shape[0], -1)
+    y, lad = np.empty_like(xf), np.empty_like(xf)
+    for e in range(xf.shape[1]):
+        cw, ch, dv = spline_tables(uw[e], uh[e], ud[e], tail_bound)
+        y[:, e], lad[:, e] = rqspline(xf[:, e], cw, ch, dv, tail_bound, inverse)
+    return y.reshape(x.shape), lad.reshape(x.shape)
+
+
 def rqspline(x, cw, ch, dv, tail_bound, inverse=False):
     """Elementwise spline / inverse spline and its log-derivative (rational_quadratic.py:20-175); returns (y, logabsdet)."""
     x = np.asarray(x, np.float64)

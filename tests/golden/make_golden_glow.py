@@ -78,7 +78,7 @@ def coupling_case(name, B, C, H, W, width, seed):
 
 
 # ---- activations (appended: SmoothLeakyRelu, SplineActivation with shared weights) ------------------------------------
-def activation_cases():
+def activation_cases(only_individual=False):
     from inf.layers.activations import SmoothLeakyRelu, SplineActivation
 
     def run(name, layer, x, extra):
@@ -97,6 +97,21 @@ def activation_cases():
         d.update(extra)
         np.savez(os.path.join(HERE, name), **d)
 
+    # SplineActivation(individual_weights=True): one set of knots per element (the MNIST Glow's activation); its own
+    # generator, so that `--individual` adds these files without rewriting the others
+    gi = torch.Generator().manual_seed(12)
+    for name, shape, nb, tb, scale in [("splinepe_b5c4_6x5_n5.npz", (5, 4, 6, 5), 5, 10.0, 6.0),
+                                       ("splinepe_b9c3_4x4_n8_tb3.npz", (9, 3, 4, 4), 8, 3.0, 2.5),
+                                       ("splinepe_b2c8_7x7_n5_tb20.npz", (2, 8, 7, 7), 5, 20.0, 9.0)]:
+        layer = SplineActivation(shape[1:], n_bins=nb, tail_bound=tb, individual_weights=True)
+        with torch.no_grad():
+            for p in layer.parameters():
+                p.copy_(torch.randn(p.shape, generator=gi) * 0.8)
+        x = torch.randn(shape, generator=gi) * scale
+        x[0, 0, 0, 0], x[0, 0, 0, 1] = tb, -tb
+        run(name, layer, x, dict(n_bins=np.int32(nb), tail_bound=np.float32(tb)))
+    if only_individual:
+        return
     g = torch.Generator().manual_seed(11)
     run("slr_b3c4_6x5.npz", SmoothLeakyRelu(0.3), torch.randn(3, 4, 6, 5, generator=g) * 3, dict(alpha=np.float32(0.3)))
     run("slr_b2c6_8x8_a01.npz", SmoothLeakyRelu(0.1), torch.randn(2, 6, 8, 8, generator=g) * 2, dict(alpha=np.float32(0.1)))
@@ -113,6 +128,9 @@ def activation_cases():
 
 
 if __name__ == "__main__":
+    if "--individual" in sys.argv:
+        activation_cases(only_individual=True)
+        sys.exit(0)
     actnorm_case("actnorm_b3c6_8x8.npz", 3, 6, 8, 8, 1, False)
     actnorm_case("actnorm_b4c5_7x5_datainit.npz", 4, 5, 7, 5, 2, True)
     actnorm_case("actnorm_b2c12_16x16.npz", 2, 12, 16, 16, 3, False)

@@ -245,6 +245,42 @@ def test_golden_spline(H, oracle, path):
     assert rel_err(host(y2), y_o) < TOL and rel_err(host(ld2), lad_o.reshape(len(y_o), -1).sum(-1)) < 2e-5
 
 
+@pytest.mark.parametrize("path", golden_files("splinepe_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_golden_spline_individual_weights(H, oracle, path):
+    """SplineActivation(individual_weights=True): the reference layer's per-element parameters loaded as they are; outputs,
+    log-det, reverse, the input gradient and the gradients of the three parameter tensors (summed over the batch) against
+    the reference's autograd; the C-ABI ops against the oracle; the same layer under bf16 autocast computes in fp32"""
+    from inf.layers.activations import SplineActivation
+    g = load_golden(path)
+    nb, tb = int(g["n_bins"]), float(g["tail_bound"])
+    layer = SplineActivation(g["x"].shape[1:], n_bins=nb, tail_bound=tb, individual_weights=True)
+    layer.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("p_")})
+    layer = layer.cuda()
+    assert layer._hip_pe(dev(g["x"]))
+    x = dev(g["x"]).requires_grad_(True)
+    y, ld = layer(x)
+    assert rel_err(host(y), g["y"]) < TOL and rel_err(host(ld), g["logdet"]) < 2e-5
+    ((y * dev(g["gy"])).sum() + (ld * dev(g["gld"])).sum()).backward()
+    assert rel_err(host(x.grad), g["gx"]) < 2e-5
+    for k, p in layer.named_parameters():
+        assert p.grad.shape == p.shape and rel_err(host(p.grad), g["g_" + k]) < 1e-4, k
+    with torch.no_grad():
+        xr = layer.reverse(y.detach())
+    assert rel_err(host(xr), g["x_rev"]) < TOL and rel_err(host(xr), g["x"]) < TOL
+    uw, uh, ud = (dev(g["p_unnormalized_" + n]) for n in ("widths", "heights", "derivatives"))
+    y2, ld2 = H.rqspline_pe(dev(g["x"]), uw, uh, ud, tb)
+    y_o, lad_o = oracle.rqspline_individual(g["x"], host(uw), host(uh), host(ud), tb)
+    assert rel_err(host(y2), y_o) < TOL and rel_err(host(ld2), lad_o.reshape(len(y_o), -1).sum(-1)) < 2e-5
+    xi, ldi = H.rqspline_pe(y2, uw, uh, ud, tb, inverse=True)
+    assert rel_err(host(xi), g["x"]) < TOL and rel_err(host(ldi), -host(ld2)) < 1e-4
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y3, _ = layer(dev(g["x"]))
+    assert y3.dtype == torch.float32 and torch.equal(y3, y.detach())
+    # empty batch
+    ye, lde = H.rqspline_pe(dev(g["x"])[:0], uw, uh, ud, tb)
+    assert ye.shape[0] == 0 and lde.shape[0] == 0
+
+
 @pytest.mark.parametrize("shape", [(4, 6, 7, 5), (16, 64, 32, 32), (3, 12, 16, 16)], ids=lambda s: "x".join(map(str, s)))
 def test_activations_against_oracle(H, oracle, shape):
     rng = np.random.default_rng(sum(shape))

@@ -27,6 +27,7 @@
 // The weight gradient of these layers (W = 8: an image row is one 8-wide k-granule) is at the end of this file.
 #include "ifl_common.h"
 #include "mfma_util.h"
+#include <atomic>
 #include <type_traits>
 
 namespace ifl {
@@ -520,9 +521,13 @@ size_t scan_team_ws_bytes(const Geom &g)
 
 static int device_cu_count()
 {
+    // (per device, read once: the attribute query costs microseconds of host time per call)
+    static std::atomic<int> cache[IFL_MAX_DEVICES];
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < IFL_MAX_DEVICES && (n = cache[dev].load(std::memory_order_relaxed)) > 0) return n;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < IFL_MAX_DEVICES) cache[dev].store(n, std::memory_order_relaxed);
     return n;
 }
 

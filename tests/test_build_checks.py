@@ -78,3 +78,20 @@ def test_compiler_leaves_the_row_buffers_alone(isa):
         lo, hi = min(row_asm), max(row_asm)
         inside = [i for i in compiler_writes if lo <= i <= hi]
         assert not inside, "%s: the compiler writes accumulator registers between the row-buffer statements (lines %s)" % (name, inside[:8])
+
+
+def test_wide_kernels_fit_their_launches(tmp_path):
+    """wide.hip: the team scan must keep its register image of the folded taps without spilling (a resident team member that
+    spills would pay a scratch round trip per diagonal), and a team member of 8 waves must fit two waves per SIMD; the fold
+    and the weight gradient do not spill either."""
+    out = str(tmp_path / "wide.s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-Wno-inline-asm", "-S",
+                    "--cuda-device-only", "-o", out, os.path.join(PKG, "csrc", "wide.hip")], check=True, stdout=subprocess.PIPE,
+                   stderr=subprocess.PIPE)
+    _, meta = kernels(open(out).read())
+    team = {k: v for k, v in meta.items() if "k_scan_team" in k}
+    assert len(team) == 12  # 3 .. 8 waves x K in {2, 3}
+    for name, m in meta.items():
+        assert m["spill"] == 0 and m["scratch"] == 0, (name, m)
+    for name, m in team.items():
+        assert m["vgpr"] <= 256, (name, m)

@@ -440,6 +440,7 @@ __global__ __launch_bounds__(NW * 64) void k_scan_team(WideScanArgs a, Geom g)
                 const int wq = d - h;
                 const bool ok = col_ok && wq >= 0 && wq < W;
                 half4 zh4, zl4;
+                float zval[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float val = ok ? zz[i] : 0.f;
@@ -449,9 +450,10 @@ __global__ __launch_bounds__(NW * 64) void k_scan_team(WideScanArgs a, Geom g)
                     const _Float16 hh = (_Float16)val;
                     zh4[i] = hh;
                     zl4[i] = (_Float16)((val - (float)hh) * LO_SCALE);
-                    if (ok) a.z[wide_pix(b, 16 * ct + 4 * q + i, h, wq, g, a.rh, a.rw)] = val;
+                    zval[i] = val;
                 }
-                // consumers: k-block ct / 2, granule 2 (ct % 2) + q / 2, halves 4 (q % 2) .. + 3
+                // consumers: k-block ct / 2, granule 2 (ct % 2) + q / 2, halves 4 (q % 2) .. + 3.  The exchange first, then the
+                // flag, then z itself: the flag waits for nothing but the two exchange stores
                 unsigned char *dst = ex + ((size_t)(d * NW + ct / 2) * 2) * 1024 + (n * 4 + 2 * (ct & 1) + (q >> 1)) * 16 + 8 * (q & 1);
                 if (!(IFL_WIDE_EXP & 4)) {
                     store_sys8(dst, __builtin_bit_cast(uintx2, zh4));
@@ -460,6 +462,10 @@ __global__ __launch_bounds__(NW * 64) void k_scan_team(WideScanArgs a, Geom g)
                 }
                 if (lane == 0 && !(IFL_WIDE_EXP & 4))
                     __hip_atomic_store(fl + (size_t)d * WIDE_NCTMAX + ct, fv, __ATOMIC_RELAXED, IFL_WIDE_SCOPE);
+                if (ok) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a.z[wide_pix(b, 16 * ct + 4 * q + i, h, wq, g, a.rh, a.rw)] = zval[i];
+                }
             }
         }
         if (s_stop) break;

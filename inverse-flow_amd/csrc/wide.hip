@@ -430,7 +430,8 @@ __global__ __launch_bounds__(NW * 64) void k_scan_team(WideScanArgs a, Geom g)
             for (int i = 0; i < 4; ++i) part[i] = acc[i] + acx[i] * LO_INV;
             red[d & 1][v][lane] = part;
             if (stop) s_stop = 1;
-            __syncthreads();
+            // (a barrier for the LDS alone: __syncthreads() also waits for every load in flight -- the x of the next diagonal)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (s_stop) break; // (uniform: written before the barrier, never cleared)
             if (v == 0) {
                 floatx4 zz = red[d & 1][0][lane];

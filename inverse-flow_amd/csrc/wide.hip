@@ -84,9 +84,18 @@ __global__ __launch_bounds__(256) void k_wide_prep(const float *__restrict__ w, 
     if (blockIdx.z > 0) { // tap t of rows 16 bi .. + 15, tap-major
         const int NS = g.KH * g.KW, t = blockIdx.z, dh = t / g.KW, dw = t % g.KW;
         float *r = rt + ((size_t)slot * NS + t) * C * C;
-        for (int idx = threadIdx.x; idx < 16 * C; idx += 256) {
-            const int kc = idx % C, c = 16 * bi + idx / C;
-            r[(size_t)c * C + kc] = dir ? w[wide_w_index(kc, c, dh, dw, g)] : w[wide_w_index(c, kc, dh, dw, g)];
+        // (sixteen elements per thread: the loads first, all in flight together, then the stores)
+        float val[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int idx = threadIdx.x + 256 * u;
+            const int kc = idx % C, c = 16 * bi + (idx / C < 16 ? idx / C : 15);
+            val[u] = dir ? w[wide_w_index(kc, c, dh, dw, g)] : w[wide_w_index(c, kc, dh, dw, g)];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int idx = threadIdx.x + 256 * u;
+            if (idx < 16 * C) r[(size_t)(16 * bi + idx / C) * C + idx % C] = val[u];
         }
         return;
     }
@@ -97,9 +106,19 @@ __global__ __launch_bounds__(256) void k_wide_prep(const float *__restrict__ w, 
     float *l = lc + (size_t)slot * C * C;
     // position p = 4 lk + c4 of a group of 16 columns holds column 4 c4 + lk: a lane's float4 at 4 lk is then its
     // A-operand element of the group's four MFMA k-chunks (k = 4 c4 + lk)
-    for (int idx = threadIdx.x; idx < 16 * C; idx += 256) {
-        const int i = 16 * bi + idx / C, p = idx % C, k = (p & ~15) + 4 * (p & 3) + ((p >> 2) & 3);
-        l[(size_t)i * C + p] = wide_l_entry(w, i, k, dir, g);
+    {
+        float val[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int idx = threadIdx.x + 256 * u;
+            const int i = 16 * bi + (idx / C < 16 ? idx / C : 15), p = idx % C, k = (p & ~15) + 4 * (p & 3) + ((p >> 2) & 3);
+            val[u] = wide_l_entry(w, i, k, dir, g);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int idx = threadIdx.x + 256 * u;
+            if (idx < 16 * C) l[(size_t)(16 * bi + idx / C) * C + idx % C] = val[u];
+        }
     }
     // the diagonal block itself, staged for the sixteen column solves
     __shared__ float blk[16][17];

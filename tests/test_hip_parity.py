@@ -593,3 +593,46 @@ def test_mailbox_regions_do_not_depend_on_the_channel_count(H):
         assert tags.max() == gen[b] - 1 and (tags.max() > 0)  # this launch's tag = generation before it + 1
         if b >= 2:
             assert set(np.unique(tags)) <= {0, 1}
+
+
+def test_wide_team_scan_streams_and_graph_replay(H, oracle):
+    """The team scan's flags carry device-side generations of the stream's state block: two streams run team scans side by
+    side, and a captured inverse + backward replays correctly any number of times."""
+    torch.manual_seed(8)
+    B, C, Hh, Ww, K = 6, 256, 8, 8, 3
+    rng = np.random.default_rng(8)
+    w = dev(_weights(rng, C, K, K, "0.01", "TL", oracle).astype(np.float32))
+    xs = [torch.randn(B, C, Hh, Ww, device="cuda") for _ in range(2)]
+    refs = [H.inverse(x, w, "TL", H.FLAG_WHOLE_IMAGE) for x in xs]  # (launch per diagonal: exact fp32)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    for it in range(5):
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                outs[k].append(H.inverse(xs[k], w))
+    torch.cuda.synchronize()
+    for k in range(2):
+        for z in outs[k]:
+            assert torch.equal(z, outs[k][0]) and rel_err(host(z), host(refs[k])) < TOL
+    s = streams[0]
+    xin, gin = xs[0].clone(), torch.randn_like(xs[0])
+    zg, dxg, dwg = torch.empty_like(xin), torch.empty_like(xin), torch.empty_like(w)
+    carry = H.new_carry(w)
+    with torch.cuda.stream(s):
+        H.inverse(xin, w, out=zg, carry=carry)
+        H.backward(gin, zg, w, dx_out=dxg, dw_out=dwg, carry=carry)
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            H.inverse(xin, w, out=zg, carry=carry)
+            H.backward(gin, zg, w, dx_out=dxg, dw_out=dwg, carry=carry)
+    for k in (0, 1, 0):
+        xin.copy_(xs[k])
+        zg.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(zg, outs[k][0]), k
+        dx_e, dw_e, _ = H.backward(gin, zg, w)
+        assert torch.equal(dxg, dx_e) and rel_err(host(dwg), host(dw_e)) < 1e-6
+    assert H.scan_voided(xin.device) == 0

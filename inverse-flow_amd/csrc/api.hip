@@ -112,15 +112,20 @@ static int run_conv(const float *in, const float *w, const float *bias, float *o
 
 // xhat = A z with the layer's effective weight (and log|det A| per image when `logdet`): two launches where the MFMA
 // convolution applies (effective weight + fp16 pack + log-det in one, then the convolution), the direct kernels otherwise
+static bool conv_eff_on_mfma(const Geom &g, unsigned flags, void *pack)
+{
+    const int pt = g.flipH ? 0 : g.KH - 1, pl = g.flipW ? 0 : g.KW - 1;
+    return pack && !(flags & (IFL_FLAG_NO_MFMA | IFL_FLAG_EXACT_F32)) && conv_mfma_supported(g.C, g.C, g.H, g.W, g.H, g.W, g.KH, g.KW, pt, pl);
+}
 static int run_conv_eff(const float *z, const float *w, float *weff, float *xhat, float *logdet, const Geom &g, unsigned flags,
-                        void *pack, hipStream_t s)
+                        void *pack, hipStream_t s, const ConvMix *mix = nullptr)
 {
     int rc;
     const int pt = g.flipH ? 0 : g.KH - 1, pl = g.flipW ? 0 : g.KW - 1; // padding corner; also the diagonal tap's stored position
     if (pack && !(flags & (IFL_FLAG_NO_MFMA | IFL_FLAG_EXACT_F32)) && conv_mfma_supported(g.C, g.C, g.H, g.W, g.H, g.W, g.KH, g.KW, pt, pl)) {
         const ConvEff eff{weff, logdet, pt, pl, g.general_diag, g.B, g.H, g.W};
         ProfScope ps(IFL_PROF_CONV, s);
-        return launch_conv_mfma(z, w, nullptr, xhat, pack, g.B, g.C, g.H, g.W, g.KH, g.KW, pt, pl, s, &eff);
+        return launch_conv_mfma(z, w, nullptr, xhat, pack, g.B, g.C, g.H, g.W, g.KH, g.KW, pt, pl, s, &eff, mix);
     }
     if ((rc = launch_effw(w, weff, g, s))) return rc;
     {
@@ -448,10 +453,16 @@ int ifl_backward_f32(const float *gout, const float *z, const float *x, const fl
         float *mix = cv.take<float>(n);
         if (!cv.ok())
             IFL_FAIL(IFL_EWORKSPACE, "ifl_backward_f32: workspace too small: need %zu bytes, have %zu", cv.off, cv.cap);
-        if ((rc = run_conv_eff(z, w, weff, az, nullptr, g, flags, pack, s))) return rc;
         // d/dW of rw*mean_b||x - A z||^2 = -(2 rw / B) sum r (x) shifted z  -> fold into the dW reduction
-        if ((rc = launch_recon_mix(u, x, az, mix, 2.0f * recon_weight / (float)B, recon_loss, 1.0f / (float)B, n, s)))
-            return rc;
+        if (conv_eff_on_mfma(g, flags, pack)) {
+            // ... in the epilogue of the convolution A z itself: the residual never exists as a tensor
+            const ConvMix mp{u, x, 2.0f * recon_weight / (float)B, recon_loss, 1.0f / (float)B};
+            if ((rc = run_conv_eff(z, w, weff, mix, nullptr, g, flags, pack, s, &mp))) return rc;
+        } else {
+            if ((rc = run_conv_eff(z, w, weff, az, nullptr, g, flags, pack, s))) return rc;
+            if ((rc = launch_recon_mix(u, x, az, mix, 2.0f * recon_weight / (float)B, recon_loss, 1.0f / (float)B, n, s)))
+                return rc;
+        }
         gsrc = mix;
     } else if (recon_loss) {
         IFL_HIP(hipMemsetAsync(recon_loss, 0, sizeof(float), s));

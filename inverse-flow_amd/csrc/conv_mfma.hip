@@ -109,7 +109,7 @@ template <int C, int KH, int KW, int WT>
 __global__ __launch_bounds__(64 * (C / 16)) void k_conv_mfma(const float *__restrict__ in, const half8 *__restrict__ apack,
                                                               const float *__restrict__ w32,
                                                               const float *__restrict__ bias, float *__restrict__ out,
-                                                              int H, int pt, int pl)
+                                                              int H, int pt, int pl, ConvMix mix)
 {
     using Cfg = ConvCfg<C, KH, KW, WT>;
     constexpr int NQ = Cfg::NQ, NT = Cfg::NT, RB = Cfg::RB, PC = Cfg::PC, PP = Cfg::PP, PB = Cfg::PB, TPR = Cfg::TPR;
@@ -122,6 +122,16 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_conv_mfma(const float *__rest
     const int band1 = band0 + Cfg::BPW < nbands ? band0 + Cfg::BPW : nbands; // this workgroup's bands [band0, band1)
     const float *inb = in + (size_t)b * C * H * WT;
     float *outb = out + (size_t)b * C * H * WT;
+    // reconstruction epilogue (ConvMix): what is stored is dx + coef (x - A z); the squared residuals are summed
+    const float *mxb = mix.x ? mix.x + (size_t)b * C * H * WT : nullptr, *mdb = mix.x ? mix.dx + (size_t)b * C * H * WT : nullptr;
+    float rsq = 0.f;
+    auto finish = [&](float v, size_t idx) -> float {
+        if (!mxb) return v;
+        float r = mxb[idx] - v;
+        r = (r == r) ? r : 0.f;
+        rsq += r * r;
+        return mdb[idx] + mix.coef * r;
+    };
 
 #ifdef IFL_STAMPS
     const unsigned long long cs0 = __builtin_amdgcn_s_memtime();
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_conv_mfma(const float *__rest
                         acc = fmaf(w32[((size_t)co * C + ci) * NT + kh * KW + kw], inb[((size_t)ci * H + ih) * WT + iw], acc);
                     }
                 }
-            outb[((size_t)co * H + oh) * WT + ow] = acc;
+            outb[((size_t)co * H + oh) * WT + ow] = finish(acc, ((size_t)co * H + oh) * WT + ow);
         }
     };
 
@@ -313,7 +323,8 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_conv_mfma(const float *__rest
             for (int T = 0; T < TPR; ++T)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    outb[((size_t)(c0 + e) * H + oh) * WT + 16 * T + n] = ahi[ro][T][e] + amid[ro][T][e] * LO_INV + bv[e];
+                    outb[((size_t)(c0 + e) * H + oh) * WT + 16 * T + n] =
+                        finish(ahi[ro][T][e] + amid[ro][T][e] * LO_INV + bv[e], ((size_t)(c0 + e) * H + oh) * WT + 16 * T + n);
         }
     };
     // Stage S: its fragments (requested during the previous stage) have landed; it multiplies while the next stage's
@@ -376,6 +387,10 @@ __global__ __launch_bounds__(64 * (C / 16)) void k_conv_mfma(const float *__rest
         }
         IFL_CSTAMP(2); // multiply + stores
     }
+    if (mix.loss) { // one atomic per wave
+        for (int o = 32; o > 0; o >>= 1) rsq += __shfl_down(rsq, o, 64);
+        if (lane == 0) atomicAdd(mix.loss, rsq * mix.loss_scale);
+    }
 #ifdef IFL_STAMPS
     if (g_cstamps && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) g_cstamps[wv] = __builtin_amdgcn_s_memtime() - cs0;
     if (g_cstamps && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
@@ -396,7 +411,7 @@ size_t conv_mfma_pack_bytes(int C, int KH, int KW) { return (size_t)KH * KW * C 
 
 template <int C, int KH, int KW, int WT>
 static int launch_conv_one(const float *in, const void *apack, const float *w, const float *bias, float *out, int B, int H,
-                           int pt, int pl, hipStream_t s)
+                           int pt, int pl, const ConvMix &mix, hipStream_t s)
 {
     using Cfg = ConvCfg<C, KH, KW, WT>;
     static LdsOptIn opt_in;
@@ -410,16 +425,17 @@ static int launch_conv_one(const float *in, const void *apack, const float *w, c
     const int nbands = (H + Cfg::RB - 1) / Cfg::RB;
     const dim3 grid((nbands + Cfg::BPW - 1) / Cfg::BPW, B);
     hipLaunchKernelGGL((k_conv_mfma<C, KH, KW, WT>), grid, dim3(Cfg::THREADS), Cfg::LDSB2, s, in, (const half8 *)apack, w,
-                       bias, out, H, pt, pl);
+                       bias, out, H, pt, pl, mix);
     IFL_HIP(hipGetLastError());
     return IFL_OK;
 }
 
 // apack: conv_mfma_pack_bytes of workspace; w: (C, C, KH, KW) fp32 (also read by the fp32 redo of a band)
 int launch_conv_mfma(const float *in, const float *w, const float *bias, float *out, void *apack, int B, int C, int H,
-                     int W, int KH, int KW, int pt, int pl, hipStream_t s, const ConvEff *eff)
+                     int W, int KH, int KW, int pt, int pl, hipStream_t s, const ConvEff *eff, const ConvMix *mix)
 {
     if (B == 0) return IFL_OK;
+    const ConvMix mx = mix ? *mix : ConvMix{nullptr, nullptr, 0.f, nullptr, 0.f};
     const size_t total = (size_t)KH * KW * C * C * 2;
     ConvEff e{nullptr, nullptr, 0, 0, 0, B, H, W};
     if (eff) e = *eff;
@@ -427,7 +443,7 @@ int launch_conv_mfma(const float *in, const float *w, const float *bias, float *
     IFL_HIP(hipGetLastError());
     if (e.weff) w = e.weff; // (the fp32 redo of a band multiplies the effective weight)
 #define IFL_CASE(CC, KK, WW) \
-    if (C == CC && KH == KK && W == WW) return launch_conv_one<CC, KK, KK, WW>(in, apack, w, bias, out, B, H, pt, pl, s);
+    if (C == CC && KH == KK && W == WW) return launch_conv_one<CC, KK, KK, WW>(in, apack, w, bias, out, B, H, pt, pl, mx, s);
     IFL_CASE(64, 3, 32)
     IFL_CASE(64, 3, 16)
     IFL_CASE(32, 3, 32)

@@ -151,8 +151,18 @@ struct ConvEff {
     int dkh, dkw, general_diag;
     int B, H, W;
 };
+// mix (optional): the reconstruction term of ifl_backward_f32 in the convolution's epilogue -- instead of A z the launch
+// stores  t = dx + coef * (x - A z)  (NaN residuals count as 0, inf/layers/selfnorm.py:212) and adds
+// loss_scale * sum (x - A z)^2 to *loss: no A z tensor, no separate pass over three activations
+struct ConvMix {
+    const float *dx, *x;
+    float coef;
+    float *loss;
+    float loss_scale;
+};
 int launch_conv_mfma(const float *in, const float *w, const float *bias, float *out, void *apack, int B, int C, int H,
-                     int W, int KH, int KW, int pt, int pl, hipStream_t s, const ConvEff *eff = nullptr);
+                     int W, int KH, int KW, int pt, int pl, hipStream_t s, const ConvEff *eff = nullptr,
+                     const ConvMix *mix = nullptr);
 
 // ---- small layers (small_layers.hip): C <= 8, image + result resident in LDS ------------------------------------
 bool scan_resident_supported(const Geom &g);

@@ -9,6 +9,7 @@ import torch
 buf = torch.zeros(4 * 8, dtype=torch.int64, device="cuda")
 os.environ["IFL_WSTAMPS"] = str(buf.data_ptr())
 import invflow_hip as H
+H.LIB_PATH = os.path.join(ROOT, "inverse-flow_amd", "lib", "libinvflow_hip_stamps.so")
 from bench import B, C, HH, WW
 z = torch.randn(B, C, HH, WW, device="cuda"); dx = torch.randn_like(z)
 for _ in range(3):

@@ -637,3 +637,26 @@ def test_wide_team_scan_streams_and_graph_replay(H, oracle):
         dx_e, dw_e, _ = H.backward(gin, zg, w)
         assert torch.equal(dxg, dx_e) and rel_err(host(dwg), host(dw_e)) < 1e-6
     assert H.scan_voided(xin.device) == voided_before
+
+
+@pytest.mark.parametrize("Hh", [1, 2, 3, 5, 15, 16, 17, 18, 19, 31])
+def test_duo_scan_row_counts(H, oracle, Hh):
+    """the duo scan at every kind of row count -- fewer rows than the first burst of row loads, one full tile, a lower tile
+    of one to three rows, a ragged lower tile -- for both channel widths, both kernel sizes and reflected orders: equal to the
+    whole-image kernel bit for bit, and to the oracle within the tolerance (forward and adjoint)"""
+    rng = np.random.default_rng(600 + Hh)
+    for (C, K, order) in ((64, 3, "TL"), (32, 2, "BR"), (64, 2, "TR"), (32, 3, "BL")):
+        B, Ww = 3, 32
+        x = rng.standard_normal((B, C, Hh, Ww)).astype(np.float32)
+        g = rng.standard_normal((B, C, Hh, Ww)).astype(np.float32)
+        w = _weights(rng, C, K, K, "0.02", order, oracle).astype(np.float32)
+        xd, gd, wd = dev(x), dev(g), dev(w)
+        z = H.inverse(xd, wd, order)
+        assert torch.equal(z, H.inverse(xd, wd, order, H.FLAG_WHOLE_IMAGE)), (Hh, C, K, order)
+        z_o = oracle.inverse(x.astype(np.float64), w.astype(np.float64), 0, order, nthreads=8)
+        assert rel_err(host(z), z_o) < TOL, (Hh, C, K, order)
+        dx, dw, _ = H.backward(gd, z, wd, order)
+        dx_w, dw_w, _ = H.backward(gd, z, wd, order, H.FLAG_WHOLE_IMAGE)
+        assert torch.equal(dx, dx_w), (Hh, C, K, order)
+        u_o = oracle.dy(g.astype(np.float64), w.astype(np.float64), 0, order, nthreads=8)
+        assert rel_err(host(dx), u_o) < TOL, (Hh, C, K, order)

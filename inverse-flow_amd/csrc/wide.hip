@@ -170,8 +170,10 @@ __global__ __launch_bounds__(256) void k_wide_fold(const float *__restrict__ rt,
     for (int i = 0; i < 4; ++i) acc[i] = doublex4{0.0, 0.0, 0.0, 0.0};
     constexpr int PFD = 3;
     floatx4 lb[PFD + 1][4];
-    floatx4 rr; // (kept as loaded: converting at the load would wait for it on the spot)
-    doublex4 dd;
+    // right-hand sides and diagonal-block inverses of this wave's (up to) four block rows: loaded once, before the loop
+    // (kept as loaded: converting at the load would wait for it on the spot)
+    floatx4 rr[4];
+    doublex4 dd[4];
     // (every load below is issued by every wave, out-of-range rows clamped to a valid one: with conditional loads the
     // compiler answers each use with vmcnt(0), which also waits for the block row requested three steps ahead)
     auto fetch_l = [&](auto bi_c) { // column block BI of L for this wave's later block rows
@@ -183,15 +185,16 @@ __global__ __launch_bounds__(256) void k_wide_fold(const float *__restrict__ rt,
             lb[BI % (PFD + 1)][a4] = *(const floatx4 *)(l + (size_t)(16 * i + li) * C + 16 * bi + 4 * lk);
         }
     };
-    auto fetch_own = [&](int bi) { // right-hand side and diagonal-block inverse of a block row this wave owns
-        if (bi >= NBK) bi = NBK - 1;
+#pragma unroll
+    for (int a4 = 0; a4 < 4; ++a4) {
+        const int bi = 4 * a4 + wv < NBK ? 4 * a4 + wv : NBK - 1;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int i = 16 * bi + 4 * v + lk, c = dir ? C - 1 - i : i;
-            rr[v] = t == 0 ? ((c == kc) ? 1.0f : 0.0f) : rtap[(size_t)c * C + kc];
-            dd[v] = di[((size_t)bi * 16 + li) * 16 + 4 * v + lk];
+            rr[a4][v] = t == 0 ? ((c == kc) ? 1.0f : 0.0f) : rtap[(size_t)c * C + kc];
+            dd[a4][v] = di[((size_t)bi * 16 + li) * 16 + 4 * v + lk];
         }
-    };
+    }
     auto step = [&](auto bi_c) {
         constexpr int BI = decltype(bi_c)::value;
         if (BI >= NBK) return; // (uniform)
@@ -199,14 +202,13 @@ __global__ __launch_bounds__(256) void k_wide_fold(const float *__restrict__ rt,
         if (wv == BI % 4) {
             doublex4 sv;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) sv[v] = (double)rr[v] - acc[BI / 4][v];
+            for (int v = 0; v < 4; ++v) sv[v] = (double)rr[BI / 4][v] - acc[BI / 4][v];
             doublex4 res = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) res = __builtin_amdgcn_mfma_f64_16x16x4f64(dd[k4], sv[k4], res, 0, 0, 0);
+            for (int k4 = 0; k4 < 4; ++k4) res = __builtin_amdgcn_mfma_f64_16x16x4f64(dd[BI / 4][k4], sv[k4], res, 0, 0, 0);
 #pragma unroll
             for (int v = 0; v < 4; ++v) xs[(16 * BI + 4 * v + lk) * XP + li] = res[v];
         }
-        fetch_own(BI + 1 + ((wv - (BI + 1)) & 3)); // this wave's next block row (requested up to four times: no branch)
         // (a barrier for the LDS alone: __syncthreads() would also wait for the loads in flight)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (BI + 1 >= NBK) return;
@@ -222,7 +224,6 @@ __global__ __launch_bounds__(256) void k_wide_fold(const float *__restrict__ rt,
                     acc[a4] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)lb[BI % (PFD + 1)][a4][c4], xb[c4], acc[a4], 0, 0, 0);
             }
     };
-    fetch_own(wv);
     fetch_l(std::integral_constant<int, 0>{});
     fetch_l(std::integral_constant<int, 1>{});
     fetch_l(std::integral_constant<int, 2>{});

@@ -140,11 +140,14 @@ __global__ __launch_bounds__(256) void k_wide_prep(const float *__restrict__ w, 
 }
 
 // ---- fold: X = L^-1 [I | W_1 | ... ] for 16 columns per workgroup -----------------------------------------------------
-// grid (C/16 column tiles, KH*KW taps, ndir), 256 threads, C*17 doubles of LDS.
-// Right-looking blocked substitution on the fp64 matrix cores (16x16x4): block row bi is finished by the inverse of its
-// diagonal block (the wave that owns it: block rows go round the four waves), published through LDS, then every later
-// block row takes its update -L[i][bi] X[bi] in its owner's accumulator.  Per block row one barrier and eight
-// dependent MFMAs; a wave's operands are loaded three steps ahead.
+// grid C/16 column tiles * KH*KW taps * ndir, 256 threads, C*17 doubles of LDS.
+// Right-looking blocked substitution on the fp64 matrix cores (16x16x4, 64 cycles each on gfx950, dependent or not:
+// tools/mfma_f64_rate_probe.hip): block row bi is finished by the inverse of its diagonal block (the wave that owns it:
+// block rows go round the four waves) and published through LDS; every later block row then takes its update
+// -L[i][bi] X[bi] in its owner's accumulator.  The update of block row bi + 1 comes first and its owner solves and
+// publishes it before the rest of its updates, so that the other waves' updates hide the solve.  One barrier per block row.
+// The column blocks of L are requested three steps ahead by loads the compiler does not see (it answers a use of a
+// load it tracks with a wait for everything in flight once branches are involved), with hand-counted waits.
 // Outputs per direction: wf32[t][kc][c] (fp32 left fold, what the general scan takes) and the scan's register image
 //   pack[ct][v][t][hl][lane] (16 B each): lane (m, q) = rows c = 16 ct + m, input channels kc = 32 v + 8 q .. + 7,
 //   +Wf_0, -Wf_t, hi = fp16(v), lo = fp16((v - hi) * 2048).
@@ -152,13 +155,32 @@ struct WideFoldOut {
     float *wf32[2];
     uintx4 *pack[2];
 };
+constexpr int fold_loads(int bi) { return bi < 15 ? 4 - (bi + 1) / 4 : 0; } // loads of column block bi per wave
+__device__ __forceinline__ void fold_load_f4(floatx4 &v, const float *p)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p));
+}
+// at most N of the loads above still in flight; redefines the four registers it guards, which keeps their uses behind it
+template <int N> __device__ __forceinline__ void fold_wait(floatx4 (&v)[4])
+{
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "n"(N));
+}
 __global__ __launch_bounds__(256) void k_wide_fold(const float *__restrict__ rt, const float *__restrict__ lc,
                                                    const double *__restrict__ dinv, WideFoldOut out, Geom g, int dir0)
 {
     extern __shared__ double xs[]; // [C][17]: row = solve-order index, column = right-hand side
     const int C = g.C, NBK = C / 16, NS = g.KH * g.KW, NW = C / 32;
-    const int jt = blockIdx.x, t = blockIdx.y, slot = blockIdx.z, dir = dir0 + slot;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane % 16, lk = lane / 16;
+    // workgroup -> (column tile, tap, direction): the taps with a full right-hand side first, tap 0 (right-hand side =
+    // identity: the block rows above the tile's own are zero and skipped) last, so that the compute units that end up with
+    // two workgroups (C = 256, 3 x 3, both directions: 288 workgroups) get a short one as the second
+    const int ndir = (int)gridDim.x / (NBK * NS), nfull = NBK * (NS - 1) * ndir, wg = blockIdx.x;
+    const int jt = wg % NBK;
+    const int t = wg < nfull ? 1 + (wg / NBK) % (NS - 1) : 0;
+    const int slot = wg < nfull ? wg / (NBK * (NS - 1)) : (wg - nfull) / NBK;
+    const int dir = dir0 + slot;
+    const int j0 = t == 0 ? (dir ? NBK - 1 - jt : jt) : 0; // first block row of X that is not zero
+    const int tid = threadIdx.x, lane = tid & 63, li = lane % 16, lk = lane / 16;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // (in a scalar register: the branches on it are scalar branches)
     const float *l = lc + (size_t)slot * C * C;
     const double *di = dinv + (size_t)slot * NBK * 256;
     const int kc = 16 * jt + li; // this lane's right-hand-side column = input channel of the tap
@@ -170,36 +192,41 @@ __global__ __launch_bounds__(256) void k_wide_fold(const float *__restrict__ rt,
     for (int i = 0; i < 4; ++i) acc[i] = doublex4{0.0, 0.0, 0.0, 0.0};
     constexpr int PFD = 3;
     floatx4 lb[PFD + 1][4];
-    // right-hand sides and diagonal-block inverses of this wave's (up to) four block rows: loaded once, before the loop
-    // (kept as loaded: converting at the load would wait for it on the spot)
-    floatx4 rr[4];
-    doublex4 dd[4];
-    // (every load below is issued by every wave, out-of-range rows clamped to a valid one: with conditional loads the
-    // compiler answers each use with vmcnt(0), which also waits for the block row requested three steps ahead)
-    auto fetch_l = [&](auto bi_c) { // column block BI of L for this wave's later block rows
+    // column block BI of L for the block rows that still take an update by it: slots (BI + 1) / 4 .. 3, none for the last
+    // block (a load whose registers nothing reads would land in whatever the compiler has put there since)
+    auto fetch_l = [&](auto bi_c) {
         constexpr int BI = decltype(bi_c)::value;
         const int bi = BI < NBK ? BI : NBK - 1;
 #pragma unroll
-        for (int a4 = 0; a4 < 4; ++a4) {
+        for (int a4 = (BI + 1) / 4; a4 < 4 && BI < 15; ++a4) {
             const int i = 4 * a4 + wv < NBK ? 4 * a4 + wv : NBK - 1;
-            lb[BI % (PFD + 1)][a4] = *(const floatx4 *)(l + (size_t)(16 * i + li) * C + 16 * bi + 4 * lk);
+            fold_load_f4(lb[BI % (PFD + 1)][a4], l + (size_t)(16 * i + li) * C + 16 * bi + 4 * lk);
         }
     };
+    fetch_l(std::integral_constant<int, 0>{});
+    fetch_l(std::integral_constant<int, 1>{});
+    fetch_l(std::integral_constant<int, 2>{});
+    // right-hand sides and diagonal-block inverses of this wave's (up to) four block rows: loaded once, before the loop
+    // (kept as loaded: converting at the load would wait for it on the spot).  Every load is issued by every wave,
+    // out-of-range rows clamped to a valid one, and tap 0 (right-hand side = identity) reads its unused slot of rt and
+    // masks the bits: a load under a condition becomes a branch with a wait for everything behind it.
+    floatx4 rr[4];
+    doublex4 dd[4];
+    const unsigned keep = t == 0 ? 0u : ~0u;
 #pragma unroll
     for (int a4 = 0; a4 < 4; ++a4) {
         const int bi = 4 * a4 + wv < NBK ? 4 * a4 + wv : NBK - 1;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int i = 16 * bi + 4 * v + lk, c = dir ? C - 1 - i : i;
-            rr[a4][v] = t == 0 ? ((c == kc) ? 1.0f : 0.0f) : rtap[(size_t)c * C + kc];
+            const unsigned ld = __float_as_uint(rtap[(size_t)c * C + kc]), id = (c == kc) ? 0x3f800000u : 0u;
+            rr[a4][v] = __uint_as_float((ld & keep) | (id & ~keep));
             dd[a4][v] = di[((size_t)bi * 16 + li) * 16 + 4 * v + lk];
         }
     }
-    auto step = [&](auto bi_c) {
+    auto solve = [&](auto bi_c) { // block row BI by its owner: X[BI] = Dinv[BI] (R[BI] - acc), into LDS
         constexpr int BI = decltype(bi_c)::value;
-        if (BI >= NBK) return; // (uniform)
-        if constexpr (BI + PFD < 16) fetch_l(std::integral_constant<int, BI + PFD>{});
-        if (wv == BI % 4) {
+        if (BI < NBK && wv == BI % 4) {
             doublex4 sv;
 #pragma unroll
             for (int v = 0; v < 4; ++v) sv[v] = (double)rr[BI / 4][v] - acc[BI / 4][v];
@@ -209,24 +236,38 @@ __global__ __launch_bounds__(256) void k_wide_fold(const float *__restrict__ rt,
 #pragma unroll
             for (int v = 0; v < 4; ++v) xs[(16 * BI + 4 * v + lk) * XP + li] = res[v];
         }
-        // (a barrier for the LDS alone: __syncthreads() would also wait for the loads in flight)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (BI + 1 >= NBK) return;
-        double xb[4];
-#pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4) xb[c4] = xs[(16 * BI + 4 * c4 + lk) * XP + li];
-#pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4)
-#pragma unroll
-            for (int a4 = 0; a4 < 4; ++a4) {
-                const int i = 4 * a4 + wv;
-                if (i > BI && i < NBK)
-                    acc[a4] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)lb[BI % (PFD + 1)][a4][c4], xb[c4], acc[a4], 0, 0, 0);
-            }
     };
-    fetch_l(std::integral_constant<int, 0>{});
-    fetch_l(std::integral_constant<int, 1>{});
-    fetch_l(std::integral_constant<int, 2>{});
+    auto step = [&](auto bi_c) { // (X[BI] is in LDS) updates by X[BI]; X[BI + 1]
+        constexpr int BI = decltype(bi_c)::value;
+        if (BI + 1 >= NBK) return; // (uniform)
+        if constexpr (BI + PFD < 16) fetch_l(std::integral_constant<int, BI + PFD>{});
+        const bool live = BI >= j0; // (uniform; X[BI] = 0 otherwise: nothing to subtract)
+        double xb[4] = {0.0, 0.0, 0.0, 0.0};
+        if (live) {
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) xb[c4] = xs[(16 * BI + 4 * c4 + lk) * XP + li];
+        }
+        fold_wait<fold_loads(BI + 1) + fold_loads(BI + 2) + fold_loads(BI + 3)>(lb[BI % (PFD + 1)]);
+        auto update = [&](auto a4_c) {
+            constexpr int A4 = decltype(a4_c)::value;
+            const int i = 4 * A4 + wv;
+            if (A4 < 4 && live && i > BI && i < NBK) {
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4)
+                    acc[A4 % 4] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)lb[BI % (PFD + 1)][A4 % 4][c4], xb[c4], acc[A4 % 4], 0, 0, 0);
+            }
+        };
+        constexpr int A0 = (BI + 1) / 4; // (block rows of the slots below A0 are done)
+        update(std::integral_constant<int, A0>{});
+        solve(std::integral_constant<int, BI + 1>{});
+        update(std::integral_constant<int, A0 + 1>{});
+        update(std::integral_constant<int, A0 + 2>{});
+        update(std::integral_constant<int, A0 + 3>{});
+        // (a barrier for the LDS alone: __syncthreads() would also wait for the loads in flight)
+        if (BI + 1 >= j0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    solve(std::integral_constant<int, 0>{});
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     step(std::integral_constant<int, 0>{});
     step(std::integral_constant<int, 1>{});
     step(std::integral_constant<int, 2>{});
@@ -242,13 +283,20 @@ __global__ __launch_bounds__(256) void k_wide_fold(const float *__restrict__ rt,
     step(std::integral_constant<int, 12>{});
     step(std::integral_constant<int, 13>{});
     step(std::integral_constant<int, 14>{});
-    step(std::integral_constant<int, 15>{});
+    // (C < 256: loads requested for block columns the matrix does not have may still be in flight, into registers that
+    // are about to be reused)
+    // (the wait names the registers: they stay allocated up to here on every path)
+    fold_wait<0>(lb[0]);
+    fold_wait<0>(lb[1]);
+    fold_wait<0>(lb[2]);
+    fold_wait<0>(lb[3]);
     __syncthreads();
-    // fp32 left fold: wf32[t][kc][c], c contiguous
+    // fp32 left fold: wf32[t][kc][c], c contiguous: a thread per c, the sixteen kc in turn
     float *wf = out.wf32[slot];
-    for (int idx = tid; idx < 16 * C; idx += 256) {
-        const int j = idx / C, c = idx % C, i = dir ? C - 1 - c : c;
-        wf[((size_t)t * C + 16 * jt + j) * C + c] = (float)xs[i * XP + j];
+    for (int c = tid; c < C; c += 256) {
+        const int i = dir ? C - 1 - c : c;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) wf[((size_t)t * C + 16 * jt + j) * C + c] = (float)xs[i * XP + j];
     }
     // the scan's register image: this workgroup holds input channels 16 jt .. + 15 = half of k-block v = jt / 2
     uintx4 *pk = out.pack[slot];
@@ -576,7 +624,7 @@ int launch_fold_team(const float *w, void *ws, const Geom &g, int dir0, int ndir
     out.pack[1] = (uintx4 *)pack1;
     float *rt = (float *)((char *)ws + wide_ws_rt_off(C));
     hipLaunchKernelGGL(k_wide_prep, dim3(g.C / 16, ndir, g.KH * g.KW), dim3(256), 0, s, w, lc, dinv, rt, g, dir0, zero0, zero1);
-    hipLaunchKernelGGL(k_wide_fold, dim3(g.C / 16, g.KH * g.KW, ndir), dim3(256), C * 17 * sizeof(double), s, rt, lc, dinv, out, g,
+    hipLaunchKernelGGL(k_wide_fold, dim3(g.C / 16 * g.KH * g.KW * ndir), dim3(256), C * 17 * sizeof(double), s, rt, lc, dinv, out, g,
                        dir0);
     IFL_HIP(hipGetLastError());
     return IFL_OK;

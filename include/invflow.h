@@ -32,6 +32,7 @@
 #define INVFLOW_H
 
 #include <stddef.h>
+#include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -139,6 +140,24 @@ int ifl_backward_f32(const float *g, const float *z, const float *x, const float
                      ifl_stream_t stream);
 
 /*
+ * bf16 storage variants (the reference dispatches its kernels on the tensor's dtype, inv_conv_with_bp_kernel_general.cu:112;
+ * "bf16 storage / fp32 accumulate").  Activations -- x, z, g, dx, xhat -- are bf16 (their 16-bit patterns);
+ * weights, weight gradients, log-determinants, the recon loss and all arithmetic are as in the f32 entry points: a call
+ * returns exactly the round-to-nearest-even bf16 of what the f32 call returns on the widened inputs.  Arguments as there;
+ * workspace from ifl_workspace_bytes_bf16 (it also holds the fp32 images the matrix-pipe kernels work on).
+ */
+size_t ifl_workspace_bytes_bf16(int op, int B, int C, int H, int W, int KH, int KW, unsigned flags);
+int ifl_inverse_bf16(const uint16_t *x, const float *w, uint16_t *z, int B, int C, int H, int W, int KH, int KW,
+                     int order, unsigned flags, void *ws, size_t ws_bytes, void *carry, void *scan_state,
+                     ifl_stream_t stream);
+int ifl_forward_bf16(const uint16_t *z, const float *w, uint16_t *xhat, float *logdet, int B, int C, int H, int W,
+                     int KH, int KW, int order, unsigned flags, void *ws, size_t ws_bytes, ifl_stream_t stream);
+int ifl_backward_bf16(const uint16_t *g, const uint16_t *z, const uint16_t *x, const float *w, uint16_t *dx, float *dw,
+                      float recon_weight, float *recon_loss, int B, int C, int H, int W, int KH, int KW,
+                      int order, unsigned flags, void *ws, size_t ws_bytes, void *carry, void *scan_state,
+                      ifl_stream_t stream);
+
+/*
  * The inverse-flow block: four layers of orders TL -> TR -> BL -> BR (Inv_FlowUnit, inf/layers/inv_flow.py:13-53).
  *   z[0] = A_TL^-1 x, z[1] = A_TR^-1 z[0], z[2] = A_BL^-1 z[1], z[3] = A_BR^-1 z[2]   (all kept: the backward needs them)
  * ONE fold launch serves the four layers (and, with carries, their adjoints), the four scans follow back to back.
@@ -213,6 +232,21 @@ int ifl_coupling_f32(const float *x, const float *h, float *y, float *logdet, in
  * gh[:,1::2] = gy2, gh[:,0::2] = (gy2 x2 exp(log_s) + g_logdet[b]) (1 - tanh^2(h_s/2)).  g_logdet may be NULL. */
 int ifl_coupling_backward_f32(const float *gy, const float *g_logdet, const float *x, const float *h, float *gx, float *gh,
                               int B, int C, int H, int W, ifl_stream_t stream);
+
+/* bf16 storage variants of the five calls above: activations (x, y, h, gy, gx, gh) as bf16, parameters, their
+ * gradients and log-determinants fp32, arithmetic and summation order as in the f32 calls (a call returns exactly the
+ * rounded result of the f32 call on the widened inputs; log-determinants and parameter gradients are bit-identical).
+ * One pass each, at half the bytes.  (ifl_actnorm_stats_f32 -- one call in a model's lifetime -- has no bf16 form.) */
+int ifl_actnorm_bf16(const uint16_t *x, const float *translation, const float *log_scale, uint16_t *y, float *logdet, int B,
+                     int C, int H, int W, int reverse, ifl_stream_t stream);
+int ifl_actnorm_backward_bf16(const uint16_t *gy, const float *g_logdet, const uint16_t *x, const float *translation,
+                              const float *log_scale, uint16_t *gx, float *g_translation, float *g_log_scale, int B, int C,
+                              int H, int W, void *ws, size_t ws_bytes, ifl_stream_t stream);
+int ifl_squeeze_bf16(const uint16_t *x, uint16_t *y, int B, int C, int H, int W, int reverse, ifl_stream_t stream);
+int ifl_coupling_bf16(const uint16_t *x, const uint16_t *h, uint16_t *y, float *logdet, int B, int C, int H, int W,
+                      int reverse, void *ws, size_t ws_bytes, ifl_stream_t stream);
+int ifl_coupling_backward_bf16(const uint16_t *gy, const float *g_logdet, const uint16_t *x, const uint16_t *h, uint16_t *gx,
+                               uint16_t *gh, int B, int C, int H, int W, ifl_stream_t stream);
 
 /* ---- activations of the Glow step (inf/layers/activations.py) ----------------------------------------------------- */
 size_t ifl_activation_workspace_bytes(int B, int C, int n_bins); /* scratch of the calls below (n_bins = 0: SmoothLeakyRelu) */

@@ -9,6 +9,7 @@
 //             (the conditioner net is three library convolutions and stays where it is: only what touches the
 //              activation elementwise is here)
 #include "ifl_common.h"
+#include "bf16_util.h"
 
 namespace ifl {
 
@@ -16,6 +17,26 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 static constexpr int GS_T = 256; // threads of every kernel here
+
+// Storage types of an activation: float, or bf16 as its 16-bit pattern (the *_bf16 entry points: SURVEY 8b dtype row,
+// "bf16 storage / fp32 accumulate").  Arithmetic is fp32 either way; with the same loop structure and summation order, so
+// that a bf16 call returns exactly the rounded result of the f32 call on the widened inputs.
+__device__ __forceinline__ void put(float *p, float v) { *p = v; }
+__device__ __forceinline__ void put(bf16_t *p, float v) { *p = narrow_bf16(v); }
+__device__ __forceinline__ f4 ld4(const float *p, int i) { return ((const f4 *)p)[i]; }
+__device__ __forceinline__ f4 ld4(const bf16_t *p, int i)
+{
+    const us4 v = ((const us4 *)p)[i];
+    return f4{widen(v[0]), widen(v[1]), widen(v[2]), widen(v[3])};
+}
+__device__ __forceinline__ void st4(float *p, int i, f4 v) { ((f4 *)p)[i] = v; }
+__device__ __forceinline__ void st4(bf16_t *p, int i, f4 v)
+{
+    ((us4 *)p)[i] = us4{narrow_bf16(v[0]), narrow_bf16(v[1]), narrow_bf16(v[2]), narrow_bf16(v[3])};
+}
+// all pointers aligned for four-element accesses of their type
+template <class T> __device__ __forceinline__ bool vec_ok(const T *a) { return (((uintptr_t)a) & (4 * sizeof(T) - 1)) == 0; }
+template <class T, class... R> __device__ __forceinline__ bool vec_ok(const T *a, const R *...r) { return vec_ok(a) && vec_ok(r...); }
 
 __device__ __forceinline__ float block_sum(float v, float *sh)
 {
@@ -29,24 +50,24 @@ __device__ __forceinline__ float block_sum(float v, float *sh)
 
 // ---- ActNorm ------------------------------------------------------------------------------------------------------
 // one workgroup per (image, channel) plane; reverse: y = x exp(ls) + t  (actnorm.py:40-54)
-__global__ __launch_bounds__(GS_T) void k_actnorm(const float *__restrict__ x, const float *__restrict__ tr,
-                                                  const float *__restrict__ ls, float *__restrict__ y, int C, int HW,
-                                                  int reverse)
+template <class T>
+__global__ __launch_bounds__(GS_T) void k_actnorm(const T *__restrict__ x, const float *__restrict__ tr,
+                                                  const float *__restrict__ ls, T *__restrict__ y, int C, int HW, int reverse)
 {
     const size_t plane = blockIdx.x;
     const int c = (int)(plane % C);
     const float t = tr[c], l = ls[c];
     const float sc = reverse ? expf(l) : expf(-l);
     const float of = reverse ? t : -t * sc; // forward: (x - t) sc = x sc - t sc
-    const float *xp = x + plane * HW;
-    float *yp = y + plane * HW;
-    if ((HW & 3) == 0 && ((((uintptr_t)xp) | ((uintptr_t)yp)) & 15) == 0) {
+    const T *xp = x + plane * HW;
+    T *yp = y + plane * HW;
+    if ((HW & 3) == 0 && vec_ok(xp, yp)) {
         for (int i = threadIdx.x; i < HW / 4; i += GS_T) {
-            const f4 v = ((const f4 *)xp)[i];
-            ((f4 *)yp)[i] = f4{fmaf(v[0], sc, of), fmaf(v[1], sc, of), fmaf(v[2], sc, of), fmaf(v[3], sc, of)};
+            const f4 v = ld4(xp, i);
+            st4(yp, i, f4{fmaf(v[0], sc, of), fmaf(v[1], sc, of), fmaf(v[2], sc, of), fmaf(v[3], sc, of)});
         }
     } else {
-        for (int i = threadIdx.x; i < HW; i += GS_T) yp[i] = fmaf(xp[i], sc, of);
+        for (int i = threadIdx.x; i < HW; i += GS_T) put(yp + i, fmaf(widen(xp[i]), sc, of));
     }
 }
 // note on rounding: the reference computes (x - t) * exp(-ls); x*sc - t*sc differs by one rounding of t*sc
@@ -64,30 +85,31 @@ __global__ __launch_bounds__(GS_T) void k_actnorm_logdet(const float *__restrict
 }
 
 // backward, stage 1: gx = gy exp(-ls); partial[plane] = {sum gy, sum gy x} over the plane
-__global__ __launch_bounds__(GS_T) void k_actnorm_bwd(const float *__restrict__ gy, const float *__restrict__ x,
-                                                      const float *__restrict__ ls, float *__restrict__ gx,
+template <class T>
+__global__ __launch_bounds__(GS_T) void k_actnorm_bwd(const T *__restrict__ gy, const T *__restrict__ x,
+                                                      const float *__restrict__ ls, T *__restrict__ gx,
                                                       float *__restrict__ partial, int C, int HW)
 {
     __shared__ float sh[4];
     const size_t plane = blockIdx.x;
     const int c = (int)(plane % C);
     const float sc = expf(-ls[c]);
-    const float *gp = gy + plane * HW, *xp = x + plane * HW;
-    float *op = gx + plane * HW;
+    const T *gp = gy + plane * HW, *xp = x + plane * HW;
+    T *op = gx + plane * HW;
     float s0 = 0.f, s1 = 0.f;
-    if ((HW & 3) == 0 && ((((uintptr_t)gp) | ((uintptr_t)xp) | ((uintptr_t)op)) & 15) == 0) {
+    if ((HW & 3) == 0 && vec_ok(gp, xp, op)) {
         for (int i = threadIdx.x; i < HW / 4; i += GS_T) {
-            const f4 g = ((const f4 *)gp)[i], v = ((const f4 *)xp)[i];
-            ((f4 *)op)[i] = g * sc;
+            const f4 g = ld4(gp, i), v = ld4(xp, i);
+            st4(op, i, g * sc);
             s0 += (g[0] + g[1]) + (g[2] + g[3]);
             s1 += (g[0] * v[0] + g[1] * v[1]) + (g[2] * v[2] + g[3] * v[3]);
         }
     } else {
         for (int i = threadIdx.x; i < HW; i += GS_T) {
-            const float g = gp[i];
-            op[i] = g * sc;
+            const float g = widen(gp[i]);
+            put(op + i, g * sc);
             s0 += g;
-            s1 += g * xp[i];
+            s1 += g * widen(xp[i]);
         }
     }
     const float t0 = block_sum(s0, sh), t1 = block_sum(s1, sh);
@@ -163,29 +185,31 @@ __global__ void k_actnorm_stats_fin(const float *__restrict__ partial, float *__
 // ---- Squeeze: y[b][4c + 2dy + dx][h2][w2] = x[b][c][2 h2 + dy][2 w2 + dx]  (squeeze.py:5-13); reverse is the inverse
 // permutation (squeeze.py:16-25).  One workgroup per (image, input channel of the large layout); a thread moves
 // four consecutive columns of the large image (two pixels of each of two small planes).
-__global__ __launch_bounds__(GS_T) void k_squeeze(const float *__restrict__ src, float *__restrict__ dst, int H, int W,
-                                                  int reverse)
+template <class E>
+__global__ __launch_bounds__(GS_T) void k_squeeze(const E *__restrict__ src, E *__restrict__ dst, int H, int W, int reverse)
 {
     // H, W: size of the LARGE image (even).  large: [plane][H][W]; small: [plane*4 + 2dy+dx][H/2][W/2]
     const size_t plane = blockIdx.x;
     const int H2 = H / 2, W2 = W / 2;
-    const float *lg_r = src + plane * H * W;       // forward reads the large layout
-    float *lg_w = dst + plane * H * W;             // reverse writes it
-    const float *sm_r = src + plane * 4 * H2 * W2; // reverse reads the small layout
-    float *sm_w = dst + plane * 4 * H2 * W2;
-    if ((W & 3) == 0 && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0) {
+    typedef E e4 __attribute__((ext_vector_type(4)));
+    typedef E e2 __attribute__((ext_vector_type(2)));
+    const E *lg_r = src + plane * H * W;       // forward reads the large layout
+    E *lg_w = dst + plane * H * W;             // reverse writes it
+    const E *sm_r = src + plane * 4 * H2 * W2; // reverse reads the small layout
+    E *sm_w = dst + plane * 4 * H2 * W2;
+    if ((W & 3) == 0 && vec_ok(src, dst)) {
         const int Q = W / 4;
         for (int i = threadIdx.x; i < H * Q; i += GS_T) {
             const int h = i / Q, q = i % Q, h2 = h >> 1, dy = h & 1;
             const size_t lo = (size_t)h * W + 4 * q;
             const size_t s0 = ((size_t)(2 * dy) * H2 + h2) * W2 + 2 * q, s1 = ((size_t)(2 * dy + 1) * H2 + h2) * W2 + 2 * q;
             if (!reverse) {
-                const f4 v = *(const f4 *)(lg_r + lo);
-                *(f2 *)(sm_w + s0) = f2{v[0], v[2]};
-                *(f2 *)(sm_w + s1) = f2{v[1], v[3]};
+                const e4 v = *(const e4 *)(lg_r + lo);
+                *(e2 *)(sm_w + s0) = e2{v[0], v[2]};
+                *(e2 *)(sm_w + s1) = e2{v[1], v[3]};
             } else {
-                const f2 a = *(const f2 *)(sm_r + s0), b = *(const f2 *)(sm_r + s1);
-                *(f4 *)(lg_w + lo) = f4{a[0], b[0], a[1], b[1]};
+                const e2 a = *(const e2 *)(sm_r + s0), b = *(const e2 *)(sm_r + s1);
+                *(e4 *)(lg_w + lo) = e4{a[0], b[0], a[1], b[1]};
             }
         }
     } else {
@@ -204,26 +228,26 @@ __global__ __launch_bounds__(GS_T) void k_squeeze(const float *__restrict__ src,
 //   forward: z2 = x2 exp(log_s) + t,  partial[b][j] = sum log_s;   reverse: z2 = (x2 - t) exp(-log_s)
 __device__ __forceinline__ float coupling_logs(float hs) { return 2.0f * tanhf(0.5f * hs); }
 
-__global__ __launch_bounds__(GS_T) void k_coupling(const float *__restrict__ x, const float *__restrict__ h,
-                                                   float *__restrict__ y, float *__restrict__ partial, int C, int HW,
-                                                   int reverse)
+template <class T>
+__global__ __launch_bounds__(GS_T) void k_coupling(const T *__restrict__ x, const T *__restrict__ h, T *__restrict__ y,
+                                                   float *__restrict__ partial, int C, int HW, int reverse)
 {
     __shared__ float sh[4];
     const int Ch = C / 2;
     const int b = blockIdx.x / Ch, j = blockIdx.x % Ch;
-    const float *x1 = x + ((size_t)b * C + j) * HW, *x2 = x + ((size_t)b * C + Ch + j) * HW;
-    const float *hs = h + ((size_t)b * C + 2 * j) * HW, *ht = hs + HW;
-    float *y1 = y + ((size_t)b * C + j) * HW, *y2 = y + ((size_t)b * C + Ch + j) * HW;
+    const T *x1 = x + ((size_t)b * C + j) * HW, *x2 = x + ((size_t)b * C + Ch + j) * HW;
+    const T *hs = h + ((size_t)b * C + 2 * j) * HW, *ht = hs + HW;
+    T *y1 = y + ((size_t)b * C + j) * HW, *y2 = y + ((size_t)b * C + Ch + j) * HW;
     float acc = 0.f;
     auto one = [&](float xv, float hsv, float htv, float &out) {
         const float l = coupling_logs(hsv);
         out = reverse ? (xv - htv) * expf(-l) : fmaf(xv, expf(l), htv);
         acc += l;
     };
-    if ((HW & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)h) | ((uintptr_t)y)) & 15) == 0) {
+    if ((HW & 3) == 0 && vec_ok(x, h, y)) {
         for (int i = threadIdx.x; i < HW / 4; i += GS_T) {
-            if (y1 != x1) ((f4 *)y1)[i] = ((const f4 *)x1)[i];
-            const f4 xv = ((const f4 *)x2)[i], a = ((const f4 *)hs)[i], t = ((const f4 *)ht)[i];
+            if (y1 != x1) st4(y1, i, ld4(x1, i)); // (a bf16 value widened and narrowed again is itself)
+            const f4 xv = ld4(x2, i), a = ld4(hs, i), t = ld4(ht, i);
             f4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -231,14 +255,14 @@ __global__ __launch_bounds__(GS_T) void k_coupling(const float *__restrict__ x, 
                 one(xv[e], a[e], t[e], r);
                 o[e] = r;
             }
-            ((f4 *)y2)[i] = o;
+            st4(y2, i, o);
         }
     } else {
         for (int i = threadIdx.x; i < HW; i += GS_T) {
             if (y1 != x1) y1[i] = x1[i];
             float r;
-            one(x2[i], hs[i], ht[i], r);
-            y2[i] = r;
+            one(widen(x2[i]), widen(hs[i]), widen(ht[i]), r);
+            put(y2 + i, r);
         }
     }
     if (!reverse && partial) {
@@ -258,28 +282,29 @@ __global__ void k_coupling_logdet(const float *__restrict__ partial, float *__re
 // backward of the forward direction: given gy (B,C,H,W) and g_logdet (B, may be NULL)
 //   gx1 = gy1 (the part through the net is the caller's: it backpropagates gh through the conditioner)
 //   gx2 = gy2 exp(log_s);  gh_t = gy2;  gh_s = (gy2 x2 exp(log_s) + g_logdet[b]) (1 - tanh^2(h_s/2))
-__global__ __launch_bounds__(GS_T) void k_coupling_bwd(const float *__restrict__ gy, const float *__restrict__ g_logdet,
-                                                       const float *__restrict__ x, const float *__restrict__ h,
-                                                       float *__restrict__ gx, float *__restrict__ gh, int C, int HW)
+template <class T>
+__global__ __launch_bounds__(GS_T) void k_coupling_bwd(const T *__restrict__ gy, const float *__restrict__ g_logdet,
+                                                       const T *__restrict__ x, const T *__restrict__ h, T *__restrict__ gx,
+                                                       T *__restrict__ gh, int C, int HW)
 {
     const int Ch = C / 2;
     const int b = blockIdx.x / Ch, j = blockIdx.x % Ch;
-    const float *g1 = gy + ((size_t)b * C + j) * HW, *g2 = gy + ((size_t)b * C + Ch + j) * HW;
-    const float *x2 = x + ((size_t)b * C + Ch + j) * HW;
-    const float *hs = h + ((size_t)b * C + 2 * j) * HW;
-    float *o1 = gx + ((size_t)b * C + j) * HW, *o2 = gx + ((size_t)b * C + Ch + j) * HW;
-    float *ghs = gh + ((size_t)b * C + 2 * j) * HW, *ght = ghs + HW;
+    const T *g1 = gy + ((size_t)b * C + j) * HW, *g2 = gy + ((size_t)b * C + Ch + j) * HW;
+    const T *x2 = x + ((size_t)b * C + Ch + j) * HW;
+    const T *hs = h + ((size_t)b * C + 2 * j) * HW;
+    T *o1 = gx + ((size_t)b * C + j) * HW, *o2 = gx + ((size_t)b * C + Ch + j) * HW;
+    T *ghs = gh + ((size_t)b * C + 2 * j) * HW, *ght = ghs + HW;
     const float gl = g_logdet ? g_logdet[b] : 0.f;
     auto one = [&](float g, float xv, float hsv, float &ox2, float &ohs) {
         const float th = tanhf(0.5f * hsv), e = expf(2.0f * th);
         ox2 = g * e;
         ohs = (g * xv * e + gl) * (1.0f - th * th);
     };
-    if ((HW & 3) == 0 && ((((uintptr_t)gy) | ((uintptr_t)x) | ((uintptr_t)h) | ((uintptr_t)gx) | ((uintptr_t)gh)) & 15) == 0) {
+    if ((HW & 3) == 0 && vec_ok(gy, x, h, gx, gh)) {
         for (int i = threadIdx.x; i < HW / 4; i += GS_T) {
-            const f4 g = ((const f4 *)g2)[i], xv = ((const f4 *)x2)[i], a = ((const f4 *)hs)[i];
-            ((f4 *)o1)[i] = ((const f4 *)g1)[i];
-            ((f4 *)ght)[i] = g;
+            const f4 g = ld4(g2, i), xv = ld4(x2, i), a = ld4(hs, i);
+            st4(o1, i, ld4(g1, i));
+            st4(ght, i, g);
             f4 ox, oh;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -288,18 +313,18 @@ __global__ __launch_bounds__(GS_T) void k_coupling_bwd(const float *__restrict__
                 ox[e] = r0;
                 oh[e] = r1;
             }
-            ((f4 *)o2)[i] = ox;
-            ((f4 *)ghs)[i] = oh;
+            st4(o2, i, ox);
+            st4(ghs, i, oh);
         }
     } else {
         for (int i = threadIdx.x; i < HW; i += GS_T) {
-            const float g = g2[i];
+            const float g = widen(g2[i]);
             float r0, r1;
-            one(g, x2[i], hs[i], r0, r1);
+            one(g, widen(x2[i]), widen(hs[i]), r0, r1);
             o1[i] = g1[i];
-            o2[i] = r0;
-            ght[i] = g;
-            ghs[i] = r1;
+            put(o2 + i, r0);
+            ght[i] = g2[i];
+            put(ghs + i, r1);
         }
     }
 }
@@ -321,39 +346,72 @@ size_t ifl_glow_workspace_bytes(int B, int C)
     return (size_t)2 * (B > 0 ? B : 0) * (C > 0 ? C : 0) * sizeof(float) + 256;
 }
 
-int ifl_actnorm_f32(const float *x, const float *translation, const float *log_scale, float *y, float *logdet, int B,
-                    int C, int H, int W, int reverse, ifl_stream_t stream)
+} // extern "C"
+
+namespace ifl {
+template <class T>
+static int actnorm_impl(const char *who, const T *x, const float *translation, const float *log_scale, T *y, float *logdet,
+                        int B, int C, int H, int W, int reverse, ifl_stream_t stream)
 {
     clear_error();
-    if (int rc = check_dims("ifl_actnorm_f32", B, C, H, W)) return rc;
+    if (int rc = check_dims(who, B, C, H, W)) return rc;
     if (B == 0) return IFL_OK;
-    if (!x || !translation || !log_scale || !y) IFL_FAIL(IFL_EINVAL, "ifl_actnorm_f32: null pointer");
+    if (!x || !translation || !log_scale || !y) IFL_FAIL(IFL_EINVAL, "%s: null pointer", who);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_actnorm, dim3((unsigned)((size_t)B * C)), dim3(GS_T), 0, s, x, translation, log_scale, y, C, H * W,
+    hipLaunchKernelGGL(k_actnorm<T>, dim3((unsigned)((size_t)B * C)), dim3(GS_T), 0, s, x, translation, log_scale, y, C, H * W,
                        reverse);
     if (logdet && !reverse) hipLaunchKernelGGL(k_actnorm_logdet, dim3(1), dim3(GS_T), 0, s, log_scale, logdet, B, C, H * W);
     IFL_HIP(hipGetLastError());
     return IFL_OK;
+}
+template <class T>
+static int actnorm_backward_impl(const char *who, const T *gy, const float *g_logdet, const T *x, const float *translation,
+                                 const float *log_scale, T *gx, float *g_translation, float *g_log_scale, int B, int C, int H,
+                                 int W, void *ws, size_t ws_bytes, ifl_stream_t stream)
+{
+    clear_error();
+    if (int rc = check_dims(who, B, C, H, W)) return rc;
+    if (!gy || !x || !translation || !log_scale || !gx) IFL_FAIL(IFL_EINVAL, "%s: null pointer", who);
+    if (ws_bytes < ifl_glow_workspace_bytes(B, C) || (!ws && B > 0))
+        IFL_FAIL(IFL_EWORKSPACE, "%s: workspace of %zu bytes needed", who, ifl_glow_workspace_bytes(B, C));
+    hipStream_t s = (hipStream_t)stream;
+    float *partial = (float *)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    if (B > 0)
+        hipLaunchKernelGGL(k_actnorm_bwd<T>, dim3((unsigned)((size_t)B * C)), dim3(GS_T), 0, s, gy, x, log_scale, gx, partial, C,
+                           H * W);
+    hipLaunchKernelGGL(k_actnorm_bwd_fin, dim3(C), dim3(64), 0, s, partial, translation, log_scale, g_logdet, g_translation,
+                       g_log_scale, B, C, H * W);
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+} // namespace ifl
+
+extern "C" {
+
+int ifl_actnorm_f32(const float *x, const float *translation, const float *log_scale, float *y, float *logdet, int B,
+                    int C, int H, int W, int reverse, ifl_stream_t stream)
+{
+    return actnorm_impl("ifl_actnorm_f32", x, translation, log_scale, y, logdet, B, C, H, W, reverse, stream);
+}
+int ifl_actnorm_bf16(const uint16_t *x, const float *translation, const float *log_scale, uint16_t *y, float *logdet, int B,
+                     int C, int H, int W, int reverse, ifl_stream_t stream)
+{
+    return actnorm_impl("ifl_actnorm_bf16", x, translation, log_scale, y, logdet, B, C, H, W, reverse, stream);
 }
 
 int ifl_actnorm_backward_f32(const float *gy, const float *g_logdet, const float *x, const float *translation,
                              const float *log_scale, float *gx, float *g_translation, float *g_log_scale, int B, int C,
                              int H, int W, void *ws, size_t ws_bytes, ifl_stream_t stream)
 {
-    clear_error();
-    if (int rc = check_dims("ifl_actnorm_backward_f32", B, C, H, W)) return rc;
-    if (!gy || !x || !translation || !log_scale || !gx) IFL_FAIL(IFL_EINVAL, "ifl_actnorm_backward_f32: null pointer");
-    if (ws_bytes < ifl_glow_workspace_bytes(B, C) || (!ws && B > 0))
-        IFL_FAIL(IFL_EWORKSPACE, "ifl_actnorm_backward_f32: workspace of %zu bytes needed", ifl_glow_workspace_bytes(B, C));
-    hipStream_t s = (hipStream_t)stream;
-    float *partial = (float *)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-    if (B > 0)
-        hipLaunchKernelGGL(k_actnorm_bwd, dim3((unsigned)((size_t)B * C)), dim3(GS_T), 0, s, gy, x, log_scale, gx, partial, C,
-                           H * W);
-    hipLaunchKernelGGL(k_actnorm_bwd_fin, dim3(C), dim3(64), 0, s, partial, translation, log_scale, g_logdet, g_translation,
-                       g_log_scale, B, C, H * W);
-    IFL_HIP(hipGetLastError());
-    return IFL_OK;
+    return actnorm_backward_impl("ifl_actnorm_backward_f32", gy, g_logdet, x, translation, log_scale, gx, g_translation,
+                                 g_log_scale, B, C, H, W, ws, ws_bytes, stream);
+}
+int ifl_actnorm_backward_bf16(const uint16_t *gy, const float *g_logdet, const uint16_t *x, const float *translation,
+                              const float *log_scale, uint16_t *gx, float *g_translation, float *g_log_scale, int B, int C,
+                              int H, int W, void *ws, size_t ws_bytes, ifl_stream_t stream)
+{
+    return actnorm_backward_impl("ifl_actnorm_backward_bf16", gy, g_logdet, x, translation, log_scale, gx, g_translation,
+                                 g_log_scale, B, C, H, W, ws, ws_bytes, stream);
 }
 
 int ifl_actnorm_stats_f32(const float *x, float *mean, float *log_std, int B, int C, int H, int W, void *ws,
@@ -373,50 +431,88 @@ int ifl_actnorm_stats_f32(const float *x, float *mean, float *log_std, int B, in
     return IFL_OK;
 }
 
-int ifl_squeeze_f32(const float *x, float *y, int B, int C, int H, int W, int reverse, ifl_stream_t stream)
+} // extern "C"
+
+namespace ifl {
+template <class E>
+static int squeeze_impl(const char *who, const E *x, E *y, int B, int C, int H, int W, int reverse, ifl_stream_t stream)
 {
     clear_error();
     /* (C, H, W): the LARGE layout -- the input of space_to_depth, the output of depth_to_space */
-    if (int rc = check_dims("ifl_squeeze_f32", B, C, H, W)) return rc;
-    if ((H | W) & 1) IFL_FAIL(IFL_EINVAL, "ifl_squeeze_f32: H=%d, W=%d must be even", H, W);
+    if (int rc = check_dims(who, B, C, H, W)) return rc;
+    if ((H | W) & 1) IFL_FAIL(IFL_EINVAL, "%s: H=%d, W=%d must be even", who, H, W);
     if (B == 0) return IFL_OK;
-    if (!x || !y || x == y) IFL_FAIL(IFL_EINVAL, "ifl_squeeze_f32: null or aliased pointers");
-    hipLaunchKernelGGL(k_squeeze, dim3((unsigned)((size_t)B * C)), dim3(GS_T), 0, (hipStream_t)stream, x, y, H, W, reverse);
+    if (!x || !y || x == y) IFL_FAIL(IFL_EINVAL, "%s: null or aliased pointers", who);
+    hipLaunchKernelGGL(k_squeeze<E>, dim3((unsigned)((size_t)B * C)), dim3(GS_T), 0, (hipStream_t)stream, x, y, H, W, reverse);
     IFL_HIP(hipGetLastError());
     return IFL_OK;
+}
+template <class T>
+static int coupling_impl(const char *who, const T *x, const T *h, T *y, float *logdet, int B, int C, int H, int W, int reverse,
+                         void *ws, size_t ws_bytes, ifl_stream_t stream)
+{
+    clear_error();
+    if (int rc = check_dims(who, B, C, H, W)) return rc;
+    if (C & 1) IFL_FAIL(IFL_EINVAL, "%s: C=%d must be even", who, C);
+    if (B == 0) return IFL_OK;
+    if (!x || !h || !y) IFL_FAIL(IFL_EINVAL, "%s: null pointer", who);
+    const bool want_ld = logdet && !reverse;
+    if (want_ld && (!ws || ws_bytes < ifl_glow_workspace_bytes(B, C)))
+        IFL_FAIL(IFL_EWORKSPACE, "%s: workspace of %zu bytes needed", who, ifl_glow_workspace_bytes(B, C));
+    hipStream_t s = (hipStream_t)stream;
+    float *partial = want_ld ? (float *)(((uintptr_t)ws + 255) & ~(uintptr_t)255) : nullptr;
+    hipLaunchKernelGGL(k_coupling<T>, dim3((unsigned)((size_t)B * (C / 2))), dim3(GS_T), 0, s, x, h, y, partial, C, H * W, reverse);
+    if (want_ld) hipLaunchKernelGGL(k_coupling_logdet, dim3((B + 63) / 64), dim3(64), 0, s, partial, logdet, B, C / 2);
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+template <class T>
+static int coupling_backward_impl(const char *who, const T *gy, const float *g_logdet, const T *x, const T *h, T *gx, T *gh, int B,
+                                  int C, int H, int W, ifl_stream_t stream)
+{
+    clear_error();
+    if (int rc = check_dims(who, B, C, H, W)) return rc;
+    if (C & 1) IFL_FAIL(IFL_EINVAL, "%s: C=%d must be even", who, C);
+    if (B == 0) return IFL_OK;
+    if (!gy || !x || !h || !gx || !gh) IFL_FAIL(IFL_EINVAL, "%s: null pointer", who);
+    hipLaunchKernelGGL(k_coupling_bwd<T>, dim3((unsigned)((size_t)B * (C / 2))), dim3(GS_T), 0, (hipStream_t)stream, gy, g_logdet, x,
+                       h, gx, gh, C, H * W);
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+} // namespace ifl
+
+extern "C" {
+
+int ifl_squeeze_f32(const float *x, float *y, int B, int C, int H, int W, int reverse, ifl_stream_t stream)
+{
+    return squeeze_impl("ifl_squeeze_f32", x, y, B, C, H, W, reverse, stream);
+}
+int ifl_squeeze_bf16(const uint16_t *x, uint16_t *y, int B, int C, int H, int W, int reverse, ifl_stream_t stream)
+{
+    return squeeze_impl("ifl_squeeze_bf16", x, y, B, C, H, W, reverse, stream);
 }
 
 int ifl_coupling_f32(const float *x, const float *h, float *y, float *logdet, int B, int C, int H, int W, int reverse,
                      void *ws, size_t ws_bytes, ifl_stream_t stream)
 {
-    clear_error();
-    if (int rc = check_dims("ifl_coupling_f32", B, C, H, W)) return rc;
-    if (C & 1) IFL_FAIL(IFL_EINVAL, "ifl_coupling_f32: C=%d must be even", C);
-    if (B == 0) return IFL_OK;
-    if (!x || !h || !y) IFL_FAIL(IFL_EINVAL, "ifl_coupling_f32: null pointer");
-    const bool want_ld = logdet && !reverse;
-    if (want_ld && (!ws || ws_bytes < ifl_glow_workspace_bytes(B, C)))
-        IFL_FAIL(IFL_EWORKSPACE, "ifl_coupling_f32: workspace of %zu bytes needed", ifl_glow_workspace_bytes(B, C));
-    hipStream_t s = (hipStream_t)stream;
-    float *partial = want_ld ? (float *)(((uintptr_t)ws + 255) & ~(uintptr_t)255) : nullptr;
-    hipLaunchKernelGGL(k_coupling, dim3((unsigned)((size_t)B * (C / 2))), dim3(GS_T), 0, s, x, h, y, partial, C, H * W, reverse);
-    if (want_ld) hipLaunchKernelGGL(k_coupling_logdet, dim3((B + 63) / 64), dim3(64), 0, s, partial, logdet, B, C / 2);
-    IFL_HIP(hipGetLastError());
-    return IFL_OK;
+    return coupling_impl("ifl_coupling_f32", x, h, y, logdet, B, C, H, W, reverse, ws, ws_bytes, stream);
+}
+int ifl_coupling_bf16(const uint16_t *x, const uint16_t *h, uint16_t *y, float *logdet, int B, int C, int H, int W, int reverse,
+                      void *ws, size_t ws_bytes, ifl_stream_t stream)
+{
+    return coupling_impl("ifl_coupling_bf16", x, h, y, logdet, B, C, H, W, reverse, ws, ws_bytes, stream);
 }
 
 int ifl_coupling_backward_f32(const float *gy, const float *g_logdet, const float *x, const float *h, float *gx, float *gh,
                               int B, int C, int H, int W, ifl_stream_t stream)
 {
-    clear_error();
-    if (int rc = check_dims("ifl_coupling_backward_f32", B, C, H, W)) return rc;
-    if (C & 1) IFL_FAIL(IFL_EINVAL, "ifl_coupling_backward_f32: C=%d must be even", C);
-    if (B == 0) return IFL_OK;
-    if (!gy || !x || !h || !gx || !gh) IFL_FAIL(IFL_EINVAL, "ifl_coupling_backward_f32: null pointer");
-    hipLaunchKernelGGL(k_coupling_bwd, dim3((unsigned)((size_t)B * (C / 2))), dim3(GS_T), 0, (hipStream_t)stream, gy, g_logdet, x,
-                       h, gx, gh, C, H * W);
-    IFL_HIP(hipGetLastError());
-    return IFL_OK;
+    return coupling_backward_impl("ifl_coupling_backward_f32", gy, g_logdet, x, h, gx, gh, B, C, H, W, stream);
+}
+int ifl_coupling_backward_bf16(const uint16_t *gy, const float *g_logdet, const uint16_t *x, const uint16_t *h, uint16_t *gx,
+                               uint16_t *gh, int B, int C, int H, int W, ifl_stream_t stream)
+{
+    return coupling_backward_impl("ifl_coupling_backward_bf16", gy, g_logdet, x, h, gx, gh, B, C, H, W, stream);
 }
 
 } // extern "C"

@@ -87,7 +87,7 @@ class ActNorm(FlowActivationLayer):
 
     def reverse(self, input, context=None):
         assert self._is_initialized()
-        if _hip_ok(input) and input.dtype == torch.float32 and not torch.is_grad_enabled():
+        if _hip_ok(input) and input.dtype in (torch.float32, torch.bfloat16) and not torch.is_grad_enabled():
             return H.actnorm(input.contiguous(), self.translation.contiguous(), self.log_scale.contiguous(), reverse=True)
         translation, log_scale = self._views(input)
         return input * torch.exp(log_scale) + translation

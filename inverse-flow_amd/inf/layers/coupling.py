@@ -53,7 +53,8 @@ class _Affine(torch.autograd.Function):
     @staticmethod
     @_fwd32
     def forward(ctx, x, h):
-        x, h = x.contiguous(), h.contiguous()
+        # (outside autocast the activation's storage format decides: bf16 activations take the bf16 entry points)
+        x, h = x.contiguous(), h.to(x.dtype).contiguous()
         ctx.save_for_backward(x, h)
         return H.coupling(x, h)
 
@@ -98,8 +99,8 @@ class Coupling(FlowLayer):
         return torch.cat([x1, torch.addcmul(t, x2, log_s.exp())], dim=1), log_s.sum(dim=(1, 2, 3))
 
     def reverse(self, input, context=None):
-        if _on_library(input) and input.dtype == torch.float32 and not torch.is_grad_enabled():
-            return H.coupling(input.contiguous(), self._conditioner(input, context).float().contiguous(), reverse=True)
+        if _on_library(input) and input.dtype in (torch.float32, torch.bfloat16) and not torch.is_grad_enabled():
+            return H.coupling(input.contiguous(), self._conditioner(input, context).to(input.dtype).contiguous(), reverse=True)
         x1, y2, log_s, t = self.get_xs_logs_t(input, context)
         return torch.cat([x1, (y2 - t) * torch.exp(-log_s)], dim=1)
 

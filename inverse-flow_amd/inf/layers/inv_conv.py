@@ -33,7 +33,9 @@ def flip_kernel(W):
 
 
 # Inside a torch.autocast region (the reference's bf16 training configs) the arithmetic of these layers stays fp32:
-# tensor arguments are cast to float32 on the way in, gradients come back in float32.
+# tensor arguments are cast to float32 on the way in, gradients come back in float32.  Outside autocast the activation's
+# storage format decides, as the reference's kernels are dispatched on the tensor's dtype: bf16 activations (weights stay
+# fp32) take the library's bf16 entry points and stay bf16.
 _fwd32 = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
 _bwd32 = torch.amp.custom_bwd(device_type="cuda")
 

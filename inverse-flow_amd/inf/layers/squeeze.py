@@ -2,7 +2,7 @@
 
 space_to_depth maps (B, C, H, W) to (B, 4C, H/2, W/2) with output channel 4c + 2dy + dx holding x[c, 2h+dy, 2w+dx]
 (the ordering of squeeze.py:5-13) -- which is torch's pixel_unshuffle with factor 2; depth_to_space is its inverse
-(pixel_shuffle).  CUDA fp32 tensors take one pass of libinvflow_hip (ifl_squeeze_f32) in either direction, and the
+(pixel_shuffle).  CUDA fp32 / bf16 tensors take one pass of libinvflow_hip (ifl_squeeze_f32 / _bf16) in either direction, and the
 gradient of one permutation is the other; everything else uses the torch primitives.  The log-det is zero."""
 import torch
 import torch.nn.functional as F
@@ -28,7 +28,7 @@ class _Permute(torch.autograd.Function):
 
 
 def _on_library(x):
-    return x.dim() == 4 and x.is_cuda and x.dtype == torch.float32
+    return x.dim() == 4 and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)
 
 
 def space_to_depth(x):

@@ -32,6 +32,10 @@ SIGNATURES = {
     "ifl_profile_collect": (_i, [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i)]),
     "ifl_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _u]),
     "ifl_inverse_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp, _vp]),
+    "ifl_workspace_bytes_bf16": (_sz, [_i, _i, _i, _i, _i, _i, _i, _u]),
+    "ifl_inverse_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp, _vp]),
+    "ifl_forward_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp]),
+    "ifl_backward_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp, _vp]),
     "ifl_unit_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _u]),
     "ifl_unit_inverse_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp, _vp]),
     "ifl_unit_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _u, _vp, _sz, _vp, _vp, _vp]),
@@ -52,6 +56,11 @@ SIGNATURES = {
     "ifl_squeeze_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ifl_coupling_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ifl_coupling_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ifl_actnorm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ifl_actnorm_backward_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "ifl_squeeze_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ifl_coupling_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "ifl_coupling_backward_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ifl_activation_workspace_bytes": (_sz, [_i, _i, _i]),
     "ifl_slr_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "ifl_slr_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
@@ -117,6 +126,14 @@ def _chk_tensor(t, name, dtype=torch.float32):
         raise RuntimeError("%s must be contiguous" % name)
     if t.dtype != dtype:
         raise RuntimeError("%s must be %s (got %s)" % (name, dtype, t.dtype))
+
+
+def _storage(t, name):
+    """("f32" | "bf16", dtype): the storage format of an activation picks the entry point, as the reference's kernels are
+    dispatched on the tensor's dtype (inv_conv_with_bp_kernel_general.cu:112)."""
+    if isinstance(t, torch.Tensor) and t.dtype == torch.bfloat16:
+        return "bf16", torch.bfloat16
+    return "f32", torch.float32
 
 
 def _same_device(*ts):
@@ -226,23 +243,24 @@ def inverse(x, w, order="TL", flags=0, out=None, carry=None):
     """z = A^-1 x.  Replaces inv_conv_with_bp.inverse (inv_conv_with_bp_general.cpp:19-28).
 
     `carry` (from new_carry) is filled for the backward call of the same step."""
-    _chk_tensor(x, "input")
+    sfx, dt = _storage(x, "input")
+    _chk_tensor(x, "input", dt)
     _chk_tensor(w, "kernel")
     B, C, H, W, KH, KW = _shape5(x, w)
     if out is None:
         out = torch.empty_like(x)
     else:
-        _chk_tensor(out, "output")
+        _chk_tensor(out, "output", dt)
         if out.shape != x.shape:
             raise RuntimeError("output shape mismatch")
     dev = _same_device(x, w, out)
     L = lib()
     with _on(dev):
-        nb = L.ifl_workspace_bytes(OP_INVERSE, B, C, H, W, KH, KW, flags)
+        nb = (L.ifl_workspace_bytes_bf16 if sfx == "bf16" else L.ifl_workspace_bytes)(OP_INVERSE, B, C, H, W, KH, KW, flags)
         ws = _ws(nb, dev)
-        rc = L.ifl_inverse_f32(_ptr(x), _ptr(w), _ptr(out), B, C, H, W, KH, KW, _order(order), flags, _ptr(ws), nb,
-                               _ptr(carry), _ptr(scan_state(dev)), _raw_stream())
-    _check(rc, "ifl_inverse_f32")
+        rc = getattr(L, "ifl_inverse_" + sfx)(_ptr(x), _ptr(w), _ptr(out), B, C, H, W, KH, KW, _order(order), flags, _ptr(ws),
+                                              nb, _ptr(carry), _ptr(scan_state(dev)), _raw_stream())
+    _check(rc, "ifl_inverse_" + sfx)
     return out
 
 
@@ -300,24 +318,25 @@ def unit_backward(g, zs, ws4, flags=0, carries=None):
 
 def forward(z, w, order="TL", flags=0, out=None, want_logdet=False):
     """xhat = A z (and log|det A| per image).  Replaces inv_conv_with_bp.forward (…general.cpp:44-53)."""
-    _chk_tensor(z, "input")
+    sfx, dt = _storage(z, "input")
+    _chk_tensor(z, "input", dt)
     _chk_tensor(w, "kernel")
     B, C, H, W, KH, KW = _shape5(z, w)
     if out is None:
         out = torch.empty_like(z)
     else:
-        _chk_tensor(out, "output")
+        _chk_tensor(out, "output", dt)
         if out.shape != z.shape:
             raise RuntimeError("output shape mismatch")
     dev = _same_device(z, w, out)
     ld = torch.empty(B, dtype=torch.float32, device=dev) if want_logdet else None
     L = lib()
     with _on(dev):
-        nb = L.ifl_workspace_bytes(OP_FORWARD, B, C, H, W, KH, KW, flags)
+        nb = (L.ifl_workspace_bytes_bf16 if sfx == "bf16" else L.ifl_workspace_bytes)(OP_FORWARD, B, C, H, W, KH, KW, flags)
         ws = _ws(nb, dev)
-        rc = L.ifl_forward_f32(_ptr(z), _ptr(w), _ptr(out), _ptr(ld), B, C, H, W, KH, KW, _order(order), flags,
-                               _ptr(ws), nb, _raw_stream())
-    _check(rc, "ifl_forward_f32")
+        rc = getattr(L, "ifl_forward_" + sfx)(_ptr(z), _ptr(w), _ptr(out), _ptr(ld), B, C, H, W, KH, KW, _order(order), flags,
+                                              _ptr(ws), nb, _raw_stream())
+    _check(rc, "ifl_forward_" + sfx)
     return (out, ld) if want_logdet else out
 
 
@@ -328,21 +347,22 @@ def backward(g, z, w, order="TL", flags=0, x=None, recon_weight=0.0, need_dx=Tru
     Replaces inv_conv_with_bp.dy + inv_conv_with_bp.dw (…general.cpp:70-112).  Returns
     (dx or None, dw or None, recon_loss tensor or None).
     """
-    _chk_tensor(g, "output_grad")
+    sfx, dt = _storage(g, "output_grad")
+    _chk_tensor(g, "output_grad", dt)
     _chk_tensor(w, "kernel")
     B, C, H, W, KH, KW = _shape5(g, w)
     if need_dw:
-        _chk_tensor(z, "z")
+        _chk_tensor(z, "z", dt)
         if z.shape != g.shape:
             raise RuntimeError("z shape mismatch")
     recon = need_dw and x is not None and recon_weight != 0.0
     if recon:
-        _chk_tensor(x, "x")
+        _chk_tensor(x, "x", dt)
     dev = _same_device(g, w, z if need_dw else None, x if recon else None)
     dx = None
     if need_dx:
         dx = dx_out if dx_out is not None else torch.empty_like(g)
-        _chk_tensor(dx, "dx")
+        _chk_tensor(dx, "dx", dt)
     dw = None
     if need_dw:
         dw = dw_out if dw_out is not None else torch.empty_like(w)
@@ -355,12 +375,14 @@ def backward(g, z, w, order="TL", flags=0, x=None, recon_weight=0.0, need_dx=Tru
             nb = L.ifl_workspace_bytes(OP_DY, B, C, H, W, KH, KW, flags)
             if need_dw:
                 nb += L.ifl_workspace_bytes(OP_DW, B, C, H, W, KH, KW, flags) + 512
+        if sfx == "bf16":
+            nb = L.ifl_workspace_bytes_bf16(OP_BACKWARD, B, C, H, W, KH, KW, flags)
         ws = _ws(nb, dev)
-        rc = L.ifl_backward_f32(_ptr(g), _ptr(z) if need_dw else None, _ptr(x) if recon else None, _ptr(w), _ptr(dx),
+        rc = getattr(L, "ifl_backward_" + sfx)(_ptr(g), _ptr(z) if need_dw else None, _ptr(x) if recon else None, _ptr(w), _ptr(dx),
                                 _ptr(dw), float(recon_weight) if recon else 0.0, _ptr(rl), B, C, H, W, KH, KW,
                                 _order(order), flags, _ptr(ws), nb, _ptr(carry), _ptr(scan_state(dev)),
                                 _raw_stream())
-    _check(rc, "ifl_backward_f32")
+    _check(rc, "ifl_backward_" + sfx)
     return dx, dw, rl
 
 
@@ -457,8 +479,8 @@ def _glow_ws(B, C, dev):
     return _ws(nb, dev), nb
 
 
-def _chk4(x, name):
-    _chk_tensor(x, name)
+def _chk4(x, name, dtype=torch.float32):
+    _chk_tensor(x, name, dtype)
     if x.dim() != 4:
         raise RuntimeError("%s must be (B, C, H, W)" % name)
     return x.shape
@@ -466,7 +488,8 @@ def _chk4(x, name):
 
 def actnorm(x, translation, log_scale, reverse=False, want_logdet=True):
     """(y, logdet) = ActNorm.forward (inf/layers/actnorm.py:18-38,59-67), or y = ActNorm.reverse (actnorm.py:40-54)."""
-    B, C, H, W = _chk4(x, "input")
+    sfx, dt = _storage(x, "input")
+    B, C, H, W = _chk4(x, "input", dt)
     _chk_tensor(translation, "translation")
     _chk_tensor(log_scale, "log_scale")
     if translation.numel() != C or log_scale.numel() != C:
@@ -475,16 +498,17 @@ def actnorm(x, translation, log_scale, reverse=False, want_logdet=True):
     y = torch.empty_like(x)
     ld = torch.empty(B, dtype=torch.float32, device=dev) if (want_logdet and not reverse) else None
     with _on(dev):
-        rc = lib().ifl_actnorm_f32(_ptr(x), _ptr(translation), _ptr(log_scale), _ptr(y), _ptr(ld), B, C, H, W,
-                                   1 if reverse else 0, _stream())
-    _check(rc, "ifl_actnorm_f32")
+        rc = getattr(lib(), "ifl_actnorm_" + sfx)(_ptr(x), _ptr(translation), _ptr(log_scale), _ptr(y), _ptr(ld), B, C, H, W,
+                                                  1 if reverse else 0, _stream())
+    _check(rc, "ifl_actnorm_" + sfx)
     return y if reverse else (y, ld)
 
 
 def actnorm_backward(gy, g_logdet, x, translation, log_scale):
     """(gx, g_translation, g_log_scale) of ActNorm.forward."""
-    B, C, H, W = _chk4(x, "input")
-    _chk_tensor(gy, "grad_output")
+    sfx, dt = _storage(x, "input")
+    B, C, H, W = _chk4(x, "input", dt)
+    _chk_tensor(gy, "grad_output", dt)
     if g_logdet is not None:
         _chk_tensor(g_logdet, "grad_logdet")
     dev = _same_device(x, gy, translation, log_scale, g_logdet)
@@ -493,9 +517,9 @@ def actnorm_backward(gy, g_logdet, x, translation, log_scale):
     gls = torch.empty(C, dtype=torch.float32, device=dev)
     with _on(dev):
         ws, nb = _glow_ws(B, C, dev)
-        rc = lib().ifl_actnorm_backward_f32(_ptr(gy), _ptr(g_logdet), _ptr(x), _ptr(translation), _ptr(log_scale), _ptr(gx),
+        rc = getattr(lib(), "ifl_actnorm_backward_" + sfx)(_ptr(gy), _ptr(g_logdet), _ptr(x), _ptr(translation), _ptr(log_scale), _ptr(gx),
                                             _ptr(gt), _ptr(gls), B, C, H, W, _ptr(ws), nb, _stream())
-    _check(rc, "ifl_actnorm_backward_f32")
+    _check(rc, "ifl_actnorm_backward_" + sfx)
     return gx, gt, gls
 
 
@@ -514,30 +538,33 @@ def actnorm_stats(x):
 
 def space_to_depth(x):
     """inf/layers/squeeze.py:5-13."""
-    B, C, H, W = _chk4(x, "input")
-    y = torch.empty(B, 4 * C, H // 2, W // 2, dtype=torch.float32, device=x.device)
+    sfx, dt = _storage(x, "input")
+    B, C, H, W = _chk4(x, "input", dt)
+    y = torch.empty(B, 4 * C, H // 2, W // 2, dtype=dt, device=x.device)
     with _on(x.device):
-        rc = lib().ifl_squeeze_f32(_ptr(x), _ptr(y), B, C, H, W, 0, _stream())
-    _check(rc, "ifl_squeeze_f32")
+        rc = getattr(lib(), "ifl_squeeze_" + sfx)(_ptr(x), _ptr(y), B, C, H, W, 0, _stream())
+    _check(rc, "ifl_squeeze_" + sfx)
     return y
 
 
 def depth_to_space(x):
     """inf/layers/squeeze.py:16-25."""
-    B, C4, H2, W2 = _chk4(x, "input")
+    sfx, dt = _storage(x, "input")
+    B, C4, H2, W2 = _chk4(x, "input", dt)
     if C4 % 4:
         raise RuntimeError("depth_to_space needs a multiple of 4 channels")
-    y = torch.empty(B, C4 // 4, 2 * H2, 2 * W2, dtype=torch.float32, device=x.device)
+    y = torch.empty(B, C4 // 4, 2 * H2, 2 * W2, dtype=dt, device=x.device)
     with _on(x.device):
-        rc = lib().ifl_squeeze_f32(_ptr(x), _ptr(y), B, C4 // 4, 2 * H2, 2 * W2, 1, _stream())
-    _check(rc, "ifl_squeeze_f32")
+        rc = getattr(lib(), "ifl_squeeze_" + sfx)(_ptr(x), _ptr(y), B, C4 // 4, 2 * H2, 2 * W2, 1, _stream())
+    _check(rc, "ifl_squeeze_" + sfx)
     return y
 
 
 def coupling(x, h, reverse=False, want_logdet=True):
     """The affine part of Coupling.forward / .reverse (inf/layers/coupling.py:66-98) given h = net(x1)."""
-    B, C, H, W = _chk4(x, "input")
-    _chk_tensor(h, "h")
+    sfx, dt = _storage(x, "input")
+    B, C, H, W = _chk4(x, "input", dt)
+    _chk_tensor(h, "h", dt)
     if h.shape != x.shape:
         raise RuntimeError("h must have the shape of the input")
     dev = _same_device(x, h)
@@ -545,26 +572,27 @@ def coupling(x, h, reverse=False, want_logdet=True):
     ld = torch.empty(B, dtype=torch.float32, device=dev) if (want_logdet and not reverse) else None
     with _on(dev):
         ws, nb = _glow_ws(B, C, dev)
-        rc = lib().ifl_coupling_f32(_ptr(x), _ptr(h), _ptr(y), _ptr(ld), B, C, H, W, 1 if reverse else 0, _ptr(ws), nb,
+        rc = getattr(lib(), "ifl_coupling_" + sfx)(_ptr(x), _ptr(h), _ptr(y), _ptr(ld), B, C, H, W, 1 if reverse else 0, _ptr(ws), nb,
                                     _stream())
-    _check(rc, "ifl_coupling_f32")
+    _check(rc, "ifl_coupling_" + sfx)
     return y if reverse else (y, ld)
 
 
 def coupling_backward(gy, g_logdet, x, h):
     """(gx_direct, gh) of the affine part of Coupling.forward; the caller backpropagates gh through the net."""
-    B, C, H, W = _chk4(x, "input")
-    _chk_tensor(gy, "grad_output")
-    _chk_tensor(h, "h")
+    sfx, dt = _storage(x, "input")
+    B, C, H, W = _chk4(x, "input", dt)
+    _chk_tensor(gy, "grad_output", dt)
+    _chk_tensor(h, "h", dt)
     if g_logdet is not None:
         _chk_tensor(g_logdet, "grad_logdet")
     dev = _same_device(x, gy, h, g_logdet)
     gx = torch.empty_like(x)
     gh = torch.empty_like(h)
     with _on(dev):
-        rc = lib().ifl_coupling_backward_f32(_ptr(gy), _ptr(g_logdet), _ptr(x), _ptr(h), _ptr(gx), _ptr(gh), B, C, H, W,
+        rc = getattr(lib(), "ifl_coupling_backward_" + sfx)(_ptr(gy), _ptr(g_logdet), _ptr(x), _ptr(h), _ptr(gx), _ptr(gh), B, C, H, W,
                                              _stream())
-    _check(rc, "ifl_coupling_backward_f32")
+    _check(rc, "ifl_coupling_backward_" + sfx)
     return gx, gh
 
 

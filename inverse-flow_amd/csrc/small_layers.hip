@@ -60,16 +60,118 @@ __global__ __launch_bounds__(256) void k_scan_resident(const float *__restrict__
     }
 }
 
+// The same sweep with the kernel size and the channel count as template arguments (2x2 / 3x3, C <= 8: every layer of the
+// reference's MNIST models): the taps unrolled, a thread's column of every folded tap in registers, no integer division
+// in the sweep (the generic kernel above spends 1.3 us per anti-diagonal, most of it in t / KW, t % KW and it % C), and z
+// kept with a zero halo of the kernel's reach above and to the left, so that no read is conditional.
+//   LDS: xs [C][H][W], zs [C][H + KH - 1][W + KW - 1], ws [NT][C][C]
+template <int KH, int KW, int C>
+__global__ __launch_bounds__(256) void k_scan_resident_t(const float *__restrict__ xin, const float *__restrict__ wf,
+                                                         float *__restrict__ zout, Geom g, int rh, int rw)
+{
+    extern __shared__ float smem[];
+    constexpr int NT = KH * KW, CP = C <= 1 ? 1 : (C <= 2 ? 2 : (C <= 4 ? 4 : 8)), LCP = CP == 1 ? 0 : (CP == 2 ? 1 : (CP == 4 ? 2 : 3));
+    const int H = g.H, W = g.W, HW = H * W, n = C * HW;
+    const int HP = H + KH - 1, WP = W + KW - 1, HWP = HP * WP;
+    float *xs = smem;
+    float *zs = xs + n;
+    float *ws = zs + C * HWP;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    // element i -> (c, h, w) by two float multiplications (exact: the quotient's rounding error, about (i / W) 2^-23, stays far
+    // below the 0.5 / W that (i + 0.5) / W keeps from an integer as long as i < 2^21; here i < 2^13); four loads in flight
+    // per thread before the first LDS write
+    const float inv_w = 1.0f / (float)W, inv_h = 1.0f / (float)H;
+    auto decode = [&](int i, int &cc, int &h, int &w) {
+        const int r = (int)(((float)i + 0.5f) * inv_w);
+        w = i - r * W;
+        cc = (int)(((float)r + 0.5f) * inv_h);
+        h = r - cc * H;
+    };
+    for (int i0 = tid; i0 < n; i0 += 1024) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 256 * u;
+            int cc, h, w;
+            decode(i < n ? i : 0, cc, h, w);
+            v[u] = xin[stored_addr(b, cc, h, w, g, rh, rw)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + 256 * u < n) xs[i0 + 256 * u] = v[u];
+    }
+    for (int i = tid; i < C * HWP; i += 256) zs[i] = 0.f;
+    for (int i = tid; i < NT * C * C; i += 256) ws[i] = wf[i];
+    __syncthreads();
+    // this thread's output channel and its column of the folded taps
+    const int c = tid & (CP - 1), j0 = tid >> LCP;
+    float wr[NT][C];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int kc = 0; kc < C; ++kc) wr[t][kc] = c < C ? ws[(t * C + kc) * C + c] : 0.f;
+    const int ND = H + W - 1;
+    for (int d = 0; d < ND; ++d) {
+        const int hmin = d - (W - 1) > 0 ? d - (W - 1) : 0;
+        const int hmax = d < H - 1 ? d : H - 1;
+        const int nh = hmax - hmin + 1;
+        if (c < C) {
+            for (int j = j0; j < nh; j += 256 / CP) {
+                const int h = hmin + j, w = d - h;
+                const float *xp = xs + h * W + w;
+                const float *zp = zs + (h + KH - 1) * WP + (w + KW - 1);
+                float acc = 0.f;
+#pragma unroll
+                for (int kc = 0; kc < C; ++kc) acc = fmaf(wr[0][kc], xp[kc * HW], acc);
+#pragma unroll
+                for (int t = 1; t < NT; ++t)
+#pragma unroll
+                    for (int kc = 0; kc < C; ++kc) acc = fmaf(-wr[t][kc], zp[kc * HWP - (t / KW) * WP - (t % KW)], acc);
+                zs[c * HWP + (h + KH - 1) * WP + (w + KW - 1)] = acc;
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += 256) {
+        int cc, h, w;
+        decode(i, cc, h, w);
+        zout[stored_addr(b, cc, h, w, g, rh, rw)] = zs[cc * HWP + (h + KH - 1) * WP + (w + KW - 1)];
+    }
+}
+
+static bool scan_resident_templated(const Geom &g)
+{
+    return g.C >= 1 && g.C <= 8 && ((g.KH == 2 && g.KW == 2) || (g.KH == 3 && g.KW == 3));
+}
+
 size_t scan_resident_lds_bytes(const Geom &g)
 {
-    return ((size_t)2 * g.C * g.H * g.W + (size_t)g.KH * g.KW * g.C * g.C) * sizeof(float);
+    const size_t zplane = scan_resident_templated(g) ? (size_t)(g.H + g.KH - 1) * (g.W + g.KW - 1) : (size_t)g.H * g.W;
+    return ((size_t)g.C * g.H * g.W + (size_t)g.C * zplane + (size_t)g.KH * g.KW * g.C * g.C) * sizeof(float);
 }
 
 bool scan_resident_supported(const Geom &g) { return g.C <= 8 && scan_resident_lds_bytes(g) <= 64 * 1024; }
 
+template <int KH, int KW> static void launch_resident_k(const float *x, const float *wf, float *z, const Geom &g, int rh, int rw,
+                                                        size_t lds, hipStream_t s)
+{
+#define IFL_RES(CC) \
+    case CC: hipLaunchKernelGGL((k_scan_resident_t<KH, KW, CC>), dim3(g.B), dim3(256), lds, s, x, wf, z, g, rh, rw); break;
+    switch (g.C) {
+        IFL_RES(1) IFL_RES(2) IFL_RES(3) IFL_RES(4) IFL_RES(5) IFL_RES(6) IFL_RES(7) IFL_RES(8)
+    }
+#undef IFL_RES
+}
+
 int launch_scan_resident(const float *x, const float *wf, float *z, const Geom &g, int rh, int rw, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_scan_resident, dim3(g.B), dim3(256), scan_resident_lds_bytes(g), s, x, wf, z, g, rh, rw);
+    const size_t lds = scan_resident_lds_bytes(g);
+    if (scan_resident_templated(g)) {
+        if (g.KH == 2) launch_resident_k<2, 2>(x, wf, z, g, rh, rw, lds, s);
+        else launch_resident_k<3, 3>(x, wf, z, g, rh, rw, lds, s);
+    } else {
+        hipLaunchKernelGGL(k_scan_resident, dim3(g.B), dim3(256), lds, s, x, wf, z, g, rh, rw);
+    }
     IFL_HIP(hipGetLastError());
     return IFL_OK;
 }

@@ -6,7 +6,10 @@ sys.path.insert(0, os.path.join(ROOT, "inverse-flow_amd")); sys.path.insert(0, R
 import torch
 import invflow_hip as H
 torch.manual_seed(0)
-for (B, C, HH, WW, K) in [(100, 12, 16, 16, 2), (100, 24, 8, 8, 2), (100, 48, 4, 4, 2)]:
+shapes = [(100, 12, 16, 16, 2), (100, 24, 8, 8, 2), (100, 48, 4, 4, 2)]
+if len(sys.argv) > 1:  # B,C,H,W,K ...
+    shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
+for (B, C, HH, WW, K) in shapes:
     w = torch.zeros(C, C, K, K); w[:, :, -1, -1] = torch.eye(C)
     w = (w + 0.01 * torch.randn(C, C, K, K)).cuda()
     x = torch.randn(B, C, HH, WW, device="cuda"); g = torch.randn_like(x)

@@ -19,4 +19,6 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_A
 echo "sq done"
 rocprofv3 --kernel-trace --stats -d $OUT/stats_wide -o stats -- python3 $ROOT/tools/prof_wide.py 16,256,8,8,3 > $OUT/stats_wide.log 2>&1
 echo "wide done"
+rocprofv3 --kernel-trace --stats -d $OUT/stats_small -o stats -- python3 $ROOT/tools/prof_small.py 64,1,28,28,3 100,4,14,14,2 100,8,7,7,2 100,12,16,16,2 100,24,8,8,2 100,48,4,4,2 > $OUT/stats_small.log 2>&1
+echo "small done"
 find $OUT -name "*.csv" | head -20

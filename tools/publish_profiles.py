@@ -32,6 +32,10 @@ if os.path.exists(os.path.join(src, "stats_wide", "stats_results.db")):
     open(os.path.join(out, name + "_rocprofv3_kernel_stats_wide_layer.txt"), "w").write(
         summary(os.path.join(src, "stats_wide", "stats_results.db")))
 
+if os.path.exists(os.path.join(src, "stats_small", "stats_results.db")):
+    open(os.path.join(out, name + "_rocprofv3_kernel_stats_small_layers.txt"), "w").write(
+        summary(os.path.join(src, "stats_small", "stats_results.db")))
+
 SCAN = r"(\S*k_scan_(?:duo|mfma)\S*)"
 m = re.search(SCAN + r"\s+(\d+)\s+([0-9.]+)", stats)
 kernel, calls, avg_us = m.group(1), int(m.group(2)), float(m.group(3))

@@ -124,3 +124,19 @@ def test_selfnorm_host_pieces():
     m = _compute_weight_multiple((4, 3, 3, 3), x, (1, 1))
     ref = torch.nn.grad.conv2d_weight(x, (4, 3, 3, 3), torch.ones(2, 4, 6, 5), 1, 1) / 2
     assert torch.allclose(m, ref)
+
+
+def test_storage_format_of_an_activation_picks_the_entry_point():
+    """invflow_hip._storage: bf16 activations -> the *_bf16 entry points, everything else -> *_f32 (whose dtype check then
+    refuses what is not float32), as the reference dispatches on the tensor's dtype (inv_conv_with_bp_kernel_general.cu:112)."""
+    import torch
+    import invflow_hip as H
+    assert H._storage(torch.zeros(1, dtype=torch.bfloat16), "x") == ("bf16", torch.bfloat16)
+    assert H._storage(torch.zeros(1), "x") == ("f32", torch.float32)
+    assert H._storage(torch.zeros(1, dtype=torch.float16), "x") == ("f32", torch.float32)
+    for name in ("ifl_inverse", "ifl_forward", "ifl_backward", "ifl_actnorm", "ifl_actnorm_backward", "ifl_squeeze", "ifl_coupling",
+                 "ifl_coupling_backward"):
+        assert name + "_bf16" in H.SIGNATURES and name + "_f32" in H.SIGNATURES
+        assert H.SIGNATURES[name + "_bf16"] == H.SIGNATURES[name + "_f32"]  # same argument lists: only the pointee differs
+    with __import__("pytest").raises(RuntimeError):
+        H.inverse(torch.zeros(1, 1, 2, 2, dtype=torch.bfloat16), torch.zeros(1, 1, 1, 1))  # CPU tensors: no fallback

@@ -15,7 +15,7 @@
 //
 // Work split: output block = 32x32 channels (one v_mfma_f32_32x32x16_f16 tile per tap), one wave owns
 // one block for a run of RPW consecutive rows of one image (its slice of the K dimension); the four
-// waves of a workgroup own four K-slices of the same block and tree-reduce through LDS, so one fp32
+// waves of a workgroup own four K-slices of the same block and sum them through LDS, so one fp32
 // partial per workgroup goes to memory (9.4 MB at the north-star shape) and a second kernel sums the
 // partials in a fixed order (deterministic; no float atomics), applies sign/scale, the gradient mask
 // (inf/layers/inv_conv.py:223-248) and the tap index map.
@@ -302,6 +302,9 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
                     if constexpr (KW > 1) As[1][ks][hl] = shift_frag<1 - CEN>(Au[ks][hl], head[ks][hl], tail[ks][hl]);
                     if constexpr (KW > 2) As[2][ks][hl] = shift_frag<2 - CEN>(Au[ks][hl], head[ks][hl], tail[ks][hl]);
                 }
+            // (letting the shifts of tap columns 1 and 2 slide into the MFMAs' shadow -- no barrier here, five VALU
+            // instructions per MFMA below -- was measured 0.8 us SLOWER; so was requesting the slice's first three rows
+            // and the halo in one go: 3400 cycles more in the prologue, with every wave of the grid asking at once)
             __builtin_amdgcn_sched_barrier(0);
             IFL_WSTAMP(1); // shifts
             // the next row's fragments
@@ -351,11 +354,14 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
     }
     IFL_WSTAMP(4);
 
-    // ---- tree reduction of the four waves' accumulators through LDS (fixed order) ----------------
-    floatx4 *red = (floatx4 *)smem; // [2][NT*4][64] float4
+    // ---- sum of the four waves' accumulators through LDS, fixed order (a0 + a2) + (a1 + a3) ---------------------------
+    // Every wave dumps its registers, one barrier, then each wave sums and stores a quarter of the vectors: the
+    // three-stage tree this replaces (two waves dump, two add, one dumps, one adds and stores: three barriers, the
+    // store by one wave) cost 7000 + 2200 of the kernel's 52000 cycles; this, 2900 + 1400.  Same additions, same order.
+    floatx4 *red = (floatx4 *)smem; // [4][NT*4][64] float4
     constexpr int NV = NT * 4;      // float4 vectors per lane
-    if (wv >= 2) {
-        floatx4 *dst = red + (size_t)(wv - 2) * NV * 64;
+    {
+        floatx4 *dst = red + (size_t)wv * NV * 64;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -363,40 +369,21 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
                 dst[(t * 4 + v) * 64 + lane] = floatx4{acc[t][4 * v], acc[t][4 * v + 1], acc[t][4 * v + 2], acc[t][4 * v + 3]};
     }
     __syncthreads();
-    if (wv < 2) {
-        const floatx4 *src = red + (size_t)wv * NV * 64;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const floatx4 o = src[(t * 4 + v) * 64 + lane];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[t][4 * v + e] += o[e];
-            }
-    }
-    __syncthreads();
-    if (wv == 1) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-                red[(t * 4 + v) * 64 + lane] = floatx4{acc[t][4 * v], acc[t][4 * v + 1], acc[t][4 * v + 2], acc[t][4 * v + 3]};
-    }
-    __syncthreads();
-    IFL_WSTAMP(5); // tree reduction
-    if (wv == 0) {
+    IFL_WSTAMP(5); // dump + barrier
+    {
         // partial[split][block][t][v][lane] (float4): the accumulator registers as they are -- register 4v+e of lane
         // (m, hh) is row (e) + 8v + 4hh, column m of the 32x32 block (C/D layout of the 32x32 MFMA); the reduce
         // kernel undoes the layout.  One 16-byte store per register quad (unscaled: the reduce kernel divides).
         floatx4 *out = (floatx4 *)partial + ((size_t)split * NB * NB + blk) * NT * 4 * 64;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const floatx4 o = red[(t * 4 + v) * 64 + lane];
-                out[(t * 4 + v) * 64 + lane] =
-                    floatx4{acc[t][4 * v] + o[0], acc[t][4 * v + 1] + o[1], acc[t][4 * v + 2] + o[2], acc[t][4 * v + 3] + o[3]};
+        for (int k = 0; k < (NV + 3) / 4; ++k) {
+            const int v = 4 * k + wv;
+            if (v < NV) {
+                const floatx4 s0 = red[(0 * NV + v) * 64 + lane], s1 = red[(1 * NV + v) * 64 + lane];
+                const floatx4 s2 = red[(2 * NV + v) * 64 + lane], s3 = red[(3 * NV + v) * 64 + lane];
+                out[v * 64 + lane] = (s0 + s2) + (s1 + s3);
             }
+        }
     }
     IFL_WSTAMP(6); // partial store
 #ifdef IFL_STAMPS
@@ -545,7 +532,7 @@ static int launch_wg(const float *a, const float *bb, float *partial, const unsi
     const int ntask = wgrad_ntask(B, H);
     const int nsplit = (ntask + 3) / 4;
     constexpr int NB = C / 32;
-    const size_t lds = (size_t)2 * KH * KW * 4 * 64 * sizeof(floatx4);
+    const size_t lds = (size_t)4 * KH * KW * 4 * 64 * sizeof(floatx4); // the four waves' accumulators
     static LdsOptIn opt_in;
     if (int rc = lds_opt_in(opt_in, (const void *)k_wgrad_mfma<C, KH, KW, NKS, CEN>, (int)lds)) return rc;
 #ifdef IFL_STAMPS

@@ -16,7 +16,7 @@ for _ in range(3):
     dw = H.dw_from(z, dx, (3, 3))
 torch.cuda.synchronize()
 t = buf.cpu().view(4, 8)
-names = ["prologue", "wait row", "convert+loads", "shift+mfma", "-", "tree reduce", "partial store", "-"]
+names = ["prologue", "wait row", "convert+loads", "shift+mfma", "-", "dump + barrier", "sum + store", "-"]
 for wv in range(4):
     r = t[wv].tolist()
     print("wave", wv, {names[k]: r[k] for k in range(7) if names[k] != "-"}, "total", sum(r))

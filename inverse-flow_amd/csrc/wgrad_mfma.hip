@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #ifdef IFL_STAMPS
     unsigned long long wst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wlast = __builtin_amdgcn_s_memtime();
+    const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime(); // (100 MHz, the same clock on every compute unit)
 #endif
 
     const int rgroups = (H + WG_RPW - 1) / WG_RPW;
@@ -389,6 +390,10 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
 #ifdef IFL_STAMPS
     if (g_wstamps && blockIdx.x == 0 && lane == 0)
         for (int k = 0; k < 8; ++k) g_wstamps[wv * 8 + k] = wst[k];
+    if (g_wstamps && tid == 0 && blockIdx.x < 1024) { // every workgroup's entry and exit on the common clock
+        g_wstamps[32 + 2 * blockIdx.x] = wg_t0;
+        g_wstamps[32 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    }
 #endif
 }
 

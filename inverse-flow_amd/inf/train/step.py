@@ -55,6 +55,7 @@ class TrainStep:
         self.bucket = dp.GradBucket(model.parameters()) if bucket else None
         self.graph, self.graph_warmup = graph, graph_warmup
         self._calls, self._captured, self._static_x, self._static_loss, self._stream = 0, None, None, None, None
+        self._ranks_agree = False  # data-dependent initialisations (ActNorm) made identical on every rank
         if graph:
             if self.bucket is None:
                 raise ValueError("TrainStep(graph=True) needs the gradient bucket (the gradients' addresses must not move)")
@@ -62,7 +63,20 @@ class TrainStep:
                 if "capturable" in group:
                     group["capturable"] = True
 
+    def _agree_on_init(self, x):
+        """ActNorm's data-dependent initialisation (actnorm.py:21-27) sees a different shard on every rank.
+        Before the first step every rank runs one forward pass without gradients -- the layers initialise themselves -- and
+        then takes rank 0's parameters and buffers, so that the replicas start, and with the averaged gradients stay,
+        identical.  (The reference's DataParallel re-broadcasts module 0's parameters on every step.)"""
+        self._ranks_agree = True
+        if dp.dist.is_available() and dp.dist.is_initialized() and dp.dist.get_world_size() > 1:
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.autocast and x.is_cuda):
+                get_loss(self.model, x)
+            dp.broadcast_parameters(self.model)
+
     def __call__(self, x):
+        if not self._ranks_agree:
+            self._agree_on_init(x)
         if not self.graph or not x.is_cuda:
             return self._eager(x)
         if self._captured is None:

@@ -75,6 +75,47 @@ def test_two_rank_gloo_allreduce(tmp_path):
     assert r.stdout.count("ok") == 2
 
 
+INIT_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+import data_parallel as dp
+from inf.layers.actnorm import ActNorm
+from inf.layers.flowsequential import FlowSequential
+from inf.train.losses import NegativeGaussianLoss
+from inf.train.step import TrainStep
+rank, local, world = dp.init("gloo")
+torch.manual_seed(7)                       # same model on both ranks ...
+model = FlowSequential(NegativeGaussianLoss((3, 4, 4)), ActNorm(3), ActNorm(3))
+step = TrainStep(model, torch.optim.SGD(model.parameters(), lr=1e-2))
+torch.manual_seed(100 + rank)              # ... different shards: the data-dependent initialisation would differ
+x = 3.0 * torch.randn(6, 3, 4, 4) + rank
+loss = step(x)
+for _ in range(2):
+    step(3.0 * torch.randn(6, 3, 4, 4) + rank)
+flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()] + [b.detach().float().reshape(-1) for b in model.buffers()])
+both = [torch.empty_like(flat) for _ in range(world)]
+dist.all_gather(both, flat)
+assert torch.equal(both[0], both[1]), (both[0] - both[1]).abs().max()   # initialised alike, stepped alike
+assert all(int(m.initialized) == 1 for m in model.modules() if isinstance(m, ActNorm))
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_first_batch_initialisation_is_rank_zeros_on_every_rank(tmp_path):
+    """SURVEY 8e: ActNorm's data-dependent initialisation is per shard; TrainStep makes rank 0's the common one before the
+    first step, and the replicas stay identical under the averaged gradients."""
+    script = tmp_path / "init_worker.py"
+    script.write_text(INIT_WORKER % (PKG, ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert r.stdout.count("ok") == 2
+
+
 def test_bench_launches_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` run plainly starts two ranks by itself (before anything touches a GPU) and rank 0's line
     says n_gpus 2; strong scaling shards the batch of 128; a process group of the wrong size is refused.  --dry: the same

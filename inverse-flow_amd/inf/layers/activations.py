@@ -117,11 +117,11 @@ def spline_tables(unnormalized_widths, unnormalized_heights, unnormalized_deriva
         cum = torch.cumsum(v, dim=-1)
         cum = F.pad(cum, pad=(1, 0), mode='constant', value=0.0)
         cum = (hi - lo) * cum + lo
-        edge = torch.zeros_like(cum)
-        edge[..., 0], edge[..., -1] = lo, hi
-        keep = torch.ones_like(cum)
-        keep[..., 0] = keep[..., -1] = 0.0
-        return cum * keep + edge  # cum[0] = lo, cum[-1] = hi without an in-place write (same values, same gradients)
+        # cum[0] = lo, cum[-1] = hi without an in-place write (same values, same gradients) and without a scalar written
+        # into a tensor element (a host-to-device copy: not capturable into a graph)
+        idx = torch.arange(cum.shape[-1], device=cum.device)
+        first, last = (idx == 0).to(cum.dtype), (idx == cum.shape[-1] - 1).to(cum.dtype)
+        return cum * (1.0 - first - last) + (lo * first + hi * last)
 
     cw = knots(unnormalized_widths, left, right, MIN_BIN_WIDTH)
     ch = knots(unnormalized_heights, bottom, top, MIN_BIN_HEIGHT)

@@ -8,7 +8,8 @@ inverse-flow layer (inf.layers.inv_conv needs the CUDA extension), the exact ope
 (already dequantised), the state_dict after the data-dependent ActNorm initialisation, the loss and every parameter's
 gradient.  Run in the build container only:
 
-    python tests/golden/make_golden_trainstep.py
+    python tests/golden/make_golden_trainstep.py            # the MNIST-Glow shape
+    python tests/golden/make_golden_trainstep.py --cifar    # the CIFAR / ImageNet-32 Glow shape (configs[3], configs[4])
 """
 import math
 import os
@@ -46,7 +47,8 @@ class StdNormal(nn.Module):
 
 
 class ExactInvFlowNoPad(nn.Module):
-    """z = A^-1 x for the TL-padded conv with the effective weight (solve_mc.py:105-109 semantics), dense, fp64."""
+    """z = A^-1 x for the TL-padded conv with the effective weight (solve_mc.py:105-109 semantics), dense, fp64.
+    (inv_flow_with_pad(order='TL') and inv_flow_no_pad are the same operator: inf/layers/inv_conv.py:94-364 / 365-513.)"""
 
     def __init__(self, C, K, gen):
         super().__init__()
@@ -70,22 +72,27 @@ class ExactInvFlowNoPad(nn.Module):
         return z, 0.0
 
 
-def main():
+def main(cifar=False):
+    """cifar=False: the if_glow_mnist shape (per-element splines, 2x2 layers, alpha 1e-7: if_glow_mnist.py:33-132);
+    cifar=True: the if_glow_cifar / if_glow_imagenet32 shape (three colour channels, 3x3 layers, ONE shared spline of 10 bins
+    and tail bound 20 per step, none behind the last step, alpha 1e-6: if_glow_cifar.py:23-100)."""
     torch.set_num_threads(4)
-    gen = torch.Generator().manual_seed(77)
-    torch.manual_seed(77)
-    B, size = 6, (1, 8, 8)
-    width, nb, tb = 16, 5, 20
-    alpha = 1e-7
+    gen = torch.Generator().manual_seed(78 if cifar else 77)
+    torch.manual_seed(78 if cifar else 77)
+    B, size = (4, (3, 8, 8)) if cifar else (6, (1, 8, 8))
+    width, nb, tb = (16, 10, 20) if cifar else (16, 5, 20)
+    alpha = 1e-6 if cifar else 1e-7
+    K = 3 if cifar else 2
     layers = [Normalization(translation=0, scale=256), Normalization(translation=-alpha, scale=1 / (1 - 2 * alpha)), LogitTransform()]
     cur = size
     for block in range(2):
         layers.append(Squeeze())
         cur = (cur[0] * 4, cur[1] // 2, cur[2] // 2)
-        for _ in range(2):
+        for k in range(2):
             layers.append(ActNorm(cur[0]))
-            layers.append(ExactInvFlowNoPad(cur[0], 2, gen))
-            layers.append(SplineActivation(cur, n_bins=nb, tail_bound=tb, individual_weights=True))
+            layers.append(ExactInvFlowNoPad(cur[0], K, gen))
+            if not (cifar and block == 1 and k == 1):
+                layers.append(SplineActivation(cur, n_bins=nb, tail_bound=tb, individual_weights=not cifar))
             layers.append(Coupling(cur, width=width))
         if block == 0:
             layers.append(SplitPrior(cur, StdNormal, width=width))
@@ -120,10 +127,10 @@ def main():
         out["sd/" + k] = v.numpy()
     for k, p in model.named_parameters():
         out["grad/" + k] = p.grad.numpy()
-    path = os.path.join(HERE, "trainstep_glow_b6_8x8_L2K2.npz")
+    path = os.path.join(HERE, "trainstep_glow_cifar_b4_8x8_L2K2.npz" if cifar else "trainstep_glow_b6_8x8_L2K2.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, "loss", float(loss), "params", sum(p.numel() for p in model.parameters()), "keys", len(out))
 
 
 if __name__ == "__main__":
-    main()
+    main(cifar="--cifar" in sys.argv)

@@ -95,3 +95,59 @@ def test_wide_kernels_fit_their_launches(tmp_path):
         assert m["spill"] == 0 and m["scratch"] == 0, (name, m)
     for name, m in team.items():
         assert m["vgpr"] <= 256, (name, m)
+
+
+def _vregs(tok):
+    """v5 -> {5}; v[4:7] -> {4, 5, 6, 7}"""
+    m = re.fullmatch(r"v(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    return set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set()
+
+
+def test_fold_never_touches_a_register_whose_load_is_in_flight(tmp_path):
+    """wide.hip, k_wide_fold: the column blocks of L arrive through loads the compiler does not see (asm) and are released by
+    hand-counted waits.  Sound only if nothing between a load and the wait that covers it reads or writes its destination
+    registers -- no copy made early, no reuse for something else.  Walks the kernel's ISA in program order with the hardware's
+    rule (loads complete in order; vmcnt(N) leaves the youngest N in flight)."""
+    out = str(tmp_path / "wide.s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-Wno-inline-asm", "-S",
+                    "--cuda-device-only", "-o", out, os.path.join(PKG, "csrc", "wide.hip")], check=True, stdout=subprocess.PIPE,
+                   stderr=subprocess.PIPE)
+    bodies, _ = kernels(open(out).read())
+    (name, lines), = [(k, v) for k, v in bodies.items() if "k_wide_fold" in k]
+    in_asm, pending, n_asm_loads, n_waits = False, [], 0, 0  # pending: destination register sets, oldest first
+    for ln in lines:
+        t = ln.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
+            continue
+        code = t.split(";")[0]
+        toks = re.findall(r"v\[\d+:\d+\]|v\d+", code)
+        used = set().union(*[_vregs(x) for x in toks]) if toks else set()
+        if in_asm and code.startswith("global_load_dwordx4"):
+            dest = _vregs(toks[0])
+            assert not (set().union(*pending) & dest if pending else set()), (name, "load into registers of a load in flight", t)
+            pending.append(dest)
+            n_asm_loads += 1
+            continue
+        m = re.search(r"vmcnt\((\d+)\)", code)
+        if code.startswith("s_waitcnt") and m:
+            n = int(m.group(1))
+            if in_asm:
+                n_waits += 1
+            # (compiler-tracked loads in flight only make the hardware wait longer than this model assumes)
+            pending = pending[len(pending) - n:] if n < len(pending) else pending
+            if n == 0:
+                pending = []
+            if in_asm:
+                continue  # the wait's own register operands are the point of it
+        busy = set().union(*pending) if pending else set()
+        assert not (used & busy), (name, "touches registers of a load in flight", t, sorted(used & busy))
+    assert n_asm_loads == 36 and n_waits == 15 + 4, (n_asm_loads, n_waits)  # 4,4,4,3,3,3,3,2,2,2,2,1,1,1,1 loads; a wait per step + 4 at the end

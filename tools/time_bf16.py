@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "inverse-flow_amd")); sys.path.insert(0, ROOT)
 import torch
 import invflow_hip as H
+if len(sys.argv) > 2 and sys.argv[1] == "--lib":
+    H.LIB_PATH = os.path.join(ROOT, "inverse-flow_amd", "lib", sys.argv[2])
 from bench import B, C, HH, WW
 
 def timed(fn, n=50):

@@ -5,9 +5,10 @@
 // are fp32.  The scans and the weight gradient are bound by the matrix pipe and by hand-off latency, not by HBM (DESIGN
 // 4.1), and their operand staging is built around 128-byte lines of fp32: a bf16 call therefore widens its inputs into
 // the caller's workspace with one streaming pass, runs the f32 path unchanged and narrows the result with another -- 6
-// bytes per element and pass, 2 x 50 MB at the north-star shape = 2 x ~8 us next to a 170 us step.  What the caller gains
-// is the halved footprint and traffic of everything around the layer (the *_bf16 kernels of glow_step.hip are single
-// passes in bf16).  A bf16 call returns exactly the rounded result of the f32 call on the widened inputs.
+// bytes per element and pass, 50 MB and 8.5-10 us each at the north-star shape: a step (x in, z out; g and z in, dx out)
+// costs 43 us more than in fp32 storage.  What the caller gains is the halved footprint and traffic of
+// everything around the layer (the *_bf16 kernels of glow_step.hip are single passes in bf16) and no casts of its own.
+// A bf16 call returns exactly the rounded result of the f32 call on the widened inputs.
 #include "ifl_common.h"
 #include "bf16_util.h"
 #include "../../include/invflow.h"
@@ -16,9 +17,16 @@ namespace ifl {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-// eight elements per thread and trip: 16 bytes of bf16, 32 bytes of fp32
-__global__ __launch_bounds__(256) void k_widen(const bf16_t *__restrict__ src, float *__restrict__ dst, size_t n)
+// eight elements per thread and trip: 16 bytes of bf16, 32 bytes of fp32; up to three tensors of one size per launch
+// (blockIdx.y: the backward widens g, z and, for the recon term, x)
+struct WidenJobs {
+    const bf16_t *src[3];
+    float *dst[3];
+};
+__global__ __launch_bounds__(256) void k_widen(WidenJobs jobs, size_t n)
 {
+    const bf16_t *__restrict__ src = jobs.src[blockIdx.y];
+    float *__restrict__ dst = jobs.dst[blockIdx.y];
     const size_t n8 = n / 8, stride = (size_t)gridDim.x * 256;
     const bool vec = ((((uintptr_t)src) & 15) | (((uintptr_t)dst) & 15)) == 0;
     if (vec) {
@@ -49,9 +57,20 @@ static unsigned stream_grid(size_t n)
     const size_t wg = (n / 8 + 255) / 256;
     return (unsigned)(wg < 1 ? 1 : (wg > 2048 ? 2048 : wg));
 }
-static void widen_to(const uint16_t *src, float *dst, size_t n, hipStream_t s)
+static void widen_to(const uint16_t *src0, float *dst0, const uint16_t *src1, float *dst1, const uint16_t *src2, float *dst2, size_t n,
+                     hipStream_t s)
 {
-    hipLaunchKernelGGL(k_widen, dim3(stream_grid(n)), dim3(256), 0, s, src, dst, n);
+    WidenJobs jobs;
+    int nj = 0;
+    const uint16_t *srcs[3] = {src0, src1, src2};
+    float *dsts[3] = {dst0, dst1, dst2};
+    for (int k = 0; k < 3; ++k)
+        if (srcs[k]) {
+            jobs.src[nj] = srcs[k];
+            jobs.dst[nj++] = dsts[k];
+        }
+    for (int k = nj; k < 3; ++k) jobs.src[k] = nullptr, jobs.dst[k] = nullptr;
+    if (nj) hipLaunchKernelGGL(k_widen, dim3(stream_grid(n), nj), dim3(256), 0, s, jobs, n);
 }
 static void narrow_to(const float *src, uint16_t *dst, size_t n, hipStream_t s)
 {
@@ -115,7 +134,7 @@ int ifl_inverse_bf16(const uint16_t *x, const float *w, uint16_t *z, int B, int 
     Staging st(ws, ws_bytes);
     float *x32 = st.take(nb), *z32 = st.take(nb);
     hipStream_t s = (hipStream_t)stream;
-    widen_to(x, x32, n, s);
+    widen_to(x, x32, nullptr, nullptr, nullptr, nullptr, n, s);
     if (int rc = ifl_inverse_f32(x32, w, z32, B, C, H, W, KH, KW, order, flags, st.p, st.left, carry, scan_state, stream)) return rc;
     narrow_to(z32, z, n, s);
     IFL_HIP(hipGetLastError());
@@ -136,7 +155,7 @@ int ifl_forward_bf16(const uint16_t *z, const float *w, uint16_t *xhat, float *l
     Staging st(ws, ws_bytes);
     float *z32 = st.take(nb), *x32 = st.take(nb);
     hipStream_t s = (hipStream_t)stream;
-    widen_to(z, z32, n, s);
+    widen_to(z, z32, nullptr, nullptr, nullptr, nullptr, n, s);
     if (int rc = ifl_forward_f32(z32, w, x32, logdet, B, C, H, W, KH, KW, order, flags, st.p, st.left, stream)) return rc;
     narrow_to(x32, xhat, n, s);
     IFL_HIP(hipGetLastError());
@@ -160,9 +179,7 @@ int ifl_backward_bf16(const uint16_t *gout, const uint16_t *z, const uint16_t *x
     Staging st(ws, ws_bytes);
     float *g32 = st.take(nb), *z32 = st.take(nb), *x32 = st.take(nb), *dx32 = st.take(nb);
     hipStream_t s = (hipStream_t)stream;
-    widen_to(gout, g32, n, s);
-    if (z) widen_to(z, z32, n, s);
-    if (x) widen_to(x, x32, n, s);
+    widen_to(gout, g32, z, z32, x, x32, n, s); // (one launch)
     // (the weight gradient contracts the fp32 dx with z: dx32 is kept even when the caller does not want dx)
     if (int rc = ifl_backward_f32(g32, z ? z32 : nullptr, x ? x32 : nullptr, w, dx32, dw, recon_weight, recon_loss, B, C, H, W, KH, KW,
                                   order, flags, st.p, st.left, carry, scan_state, stream))

@@ -263,7 +263,7 @@ int ifl_slr_backward_f32(const float *gy, const float *g_logdet, const float *x,
 /* SplineActivation with shared weights (activations.py:126-217): the monotone rational-quadratic spline with linear
  * tails of inf/layers/splines/rational_quadratic.py:20-175 on knot tables cw, ch (positions, cw[0] = ch[0] =
  * -tail_bound, cw[n_bins] = ch[n_bins] = +tail_bound) and dv (derivatives): DEVICE arrays of n_bins + 1 floats, computed
- * from the layer's parameters by the caller (rational_quadratic.py:97-116; no host round trip).  n_bins <= 8.
+ * from the layer's parameters by the caller (rational_quadratic.py:97-116; no host round trip).  n_bins <= 16 (per-element form: <= 8).
  * inverse = 0: y = spline(x), logdet[b] = sum log|dy/dx| (may be NULL);  inverse != 0: y = spline^-1(x), logdet[b] =
  * sum log|dy/dx| of the inverse map. */
 /* the knot tables from the layer's parameters (DEVICE vectors: unnormalized widths and heights of n_bins entries,

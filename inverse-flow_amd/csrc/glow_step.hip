@@ -586,7 +586,8 @@ __global__ void k_plane_sums(const float *__restrict__ partial, float *__restric
 
 // ---- rational-quadratic spline with linear tails (splines/rational_quadratic.py:20-175), shared knots ---------------
 // cw, ch: NB + 1 knot positions (cw[0] = ch[0] = -tail, cw[NB] = ch[NB] = +tail), dv: NB + 1 knot derivatives.
-static constexpr int RQ_MAXB = 8;
+static constexpr int RQ_MAXB = 16;   // shared knots (the reference's 32x32x3 builders use 10 bins: if_glow_cifar.py:23-26)
+static constexpr int RQ_PE_MAXB = 8; // one set of knots per element (the MNIST builder uses 5)
 struct RqTables {
     float cw[RQ_MAXB + 1], ch[RQ_MAXB + 1], dv[RQ_MAXB + 1];
 };
@@ -1146,7 +1147,10 @@ int ifl_rqspline_f32(const float *x, const float *cw, const float *ch, const flo
     const dim3 grid((unsigned)((size_t)B * C));
 #define IFL_RQ(NB) \
     case NB: hipLaunchKernelGGL(k_rqspline<NB>, grid, dim3(GS_T), 0, s, x, y, partial, cw, ch, dv, H * W, tail_bound, inverse); break;
-    switch (n_bins) { IFL_RQ(1) IFL_RQ(2) IFL_RQ(3) IFL_RQ(4) IFL_RQ(5) IFL_RQ(6) IFL_RQ(7) IFL_RQ(8) }
+    switch (n_bins) {
+        IFL_RQ(1) IFL_RQ(2) IFL_RQ(3) IFL_RQ(4) IFL_RQ(5) IFL_RQ(6) IFL_RQ(7) IFL_RQ(8)
+        IFL_RQ(9) IFL_RQ(10) IFL_RQ(11) IFL_RQ(12) IFL_RQ(13) IFL_RQ(14) IFL_RQ(15) IFL_RQ(16)
+    }
 #undef IFL_RQ
     if (logdet) hipLaunchKernelGGL(k_plane_sums, dim3((B + 63) / 64), dim3(64), 0, s, partial, logdet, B, C);
     IFL_HIP(hipGetLastError());
@@ -1171,7 +1175,10 @@ int ifl_rqspline_backward_f32(const float *gy, const float *g_logdet, const floa
         const dim3 grid((unsigned)planes);
 #define IFL_RQ(NB) \
     case NB: hipLaunchKernelGGL(k_rqspline_bwd<NB>, grid, dim3(GS_T), 0, s, gy, g_logdet, x, gx, tpart, cw, ch, dv, C, H * W, tail_bound); break;
-        switch (n_bins) { IFL_RQ(1) IFL_RQ(2) IFL_RQ(3) IFL_RQ(4) IFL_RQ(5) IFL_RQ(6) IFL_RQ(7) IFL_RQ(8) }
+        switch (n_bins) {
+            IFL_RQ(1) IFL_RQ(2) IFL_RQ(3) IFL_RQ(4) IFL_RQ(5) IFL_RQ(6) IFL_RQ(7) IFL_RQ(8)
+            IFL_RQ(9) IFL_RQ(10) IFL_RQ(11) IFL_RQ(12) IFL_RQ(13) IFL_RQ(14) IFL_RQ(15) IFL_RQ(16)
+        }
 #undef IFL_RQ
     }
     hipLaunchKernelGGL(k_table_sums, dim3(3 * (n_bins + 1)), dim3(64), 0, s, tpart, g_tables, planes, 3 * (n_bins + 1));
@@ -1191,7 +1198,7 @@ int ifl_rqspline_pe_f32(const float *x, const float *uw, const float *uh, const 
 {
     clear_error();
     if (B < 0 || P < 1) IFL_FAIL(IFL_EINVAL, "ifl_rqspline_pe_f32: bad shape B=%d P=%d", B, P);
-    if (n_bins < 1 || n_bins > RQ_MAXB) IFL_FAIL(IFL_EUNSUPPORTED, "ifl_rqspline_pe_f32: n_bins=%d (1..%d supported)", n_bins, RQ_MAXB);
+    if (n_bins < 1 || n_bins > RQ_PE_MAXB) IFL_FAIL(IFL_EUNSUPPORTED, "ifl_rqspline_pe_f32: n_bins=%d (1..%d supported)", n_bins, RQ_PE_MAXB);
     if (B == 0) return IFL_OK;
     if (!x || !y || !uw || !uh || (!ud && n_bins > 1)) IFL_FAIL(IFL_EINVAL, "ifl_rqspline_pe_f32: null pointer");
     if (logdet && (!ws || ws_bytes < ifl_rqspline_pe_workspace_bytes(B, P, n_bins)))
@@ -1217,8 +1224,8 @@ int ifl_rqspline_pe_backward_f32(const float *gy, const float *g_logdet, const f
 {
     clear_error();
     if (B < 0 || P < 1) IFL_FAIL(IFL_EINVAL, "ifl_rqspline_pe_backward_f32: bad shape B=%d P=%d", B, P);
-    if (n_bins < 1 || n_bins > RQ_MAXB)
-        IFL_FAIL(IFL_EUNSUPPORTED, "ifl_rqspline_pe_backward_f32: n_bins=%d (1..%d supported)", n_bins, RQ_MAXB);
+    if (n_bins < 1 || n_bins > RQ_PE_MAXB)
+        IFL_FAIL(IFL_EUNSUPPORTED, "ifl_rqspline_pe_backward_f32: n_bins=%d (1..%d supported)", n_bins, RQ_PE_MAXB);
     if (!g_params) IFL_FAIL(IFL_EINVAL, "ifl_rqspline_pe_backward_f32: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const size_t n = (size_t)P * (3 * (size_t)n_bins - 1);

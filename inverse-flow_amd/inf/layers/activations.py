@@ -206,11 +206,11 @@ class SplineActivation(FlowActivationLayer):
             self.unnormalized_derivatives = torch.nn.Parameter(torch.randn(n_bins - 1) * 0.01)
 
     def _hip(self, input):
-        return _hip_ok(input) and not self.individual_weights and 1 <= self.n_bins <= 8
+        return _hip_ok(input) and not self.individual_weights and 1 <= self.n_bins <= 16
 
     def _tables(self):
         p = self.unnormalized_widths
-        if (p.is_cuda and p.dtype == torch.float32 and not self.individual_weights and 2 <= self.n_bins <= 8
+        if (p.is_cuda and p.dtype == torch.float32 and not self.individual_weights and 2 <= self.n_bins <= 16
                 and not os.environ.get("IFL_TORCH_SPLINE_TABLES")):  # (the switch is for A/B timing)
             return _TablesFn.apply(self.unnormalized_widths, self.unnormalized_heights, self.unnormalized_derivatives,
                                    float(self.tail_bound))

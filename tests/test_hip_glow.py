@@ -320,12 +320,52 @@ def test_activations_against_oracle(H, oracle, shape):
         assert rel_err(host(p.grad), q.grad.numpy()) < 1e-4, k
 
 
+@pytest.mark.parametrize("nb,tb", [(10, 20.0), (16, 8.0), (9, 3.0)], ids=str)
+def test_shared_spline_of_the_32x32_builders(H, oracle, nb, tb):
+    """The 32x32x3 models' activation: ONE set of knots, 10 bins, tail bound 20 (if_glow_cifar.py:23-26) -- more bins than the
+    per-element spline of the MNIST model.  Library kernels against the oracle (values, log-derivative, inverse) and against
+    autograd through the torch expressions of the same spline in float64 (input and parameter gradients)."""
+    from inf.layers.activations import SplineActivation, _spline_torch
+    shape = (3, 12, 16, 16)
+    rng = np.random.default_rng(nb)
+    x = (rng.standard_normal(shape) * 0.6 * tb).astype(np.float32)  # (some elements in the linear tails)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    gld = rng.standard_normal(shape[0]).astype(np.float32)
+    uw, uh, ud = rng.standard_normal(nb), rng.standard_normal(nb), rng.standard_normal(nb - 1)
+    cw, ch, dv = oracle.spline_tables(uw, uh, ud, tb)
+    s, sl = H.rqspline(dev(x), dev(cw), dev(ch), dev(dv), tb)
+    s_o, lad_o = oracle.rqspline(x, cw, ch, dv, tb)
+    assert rel_err(host(s), s_o) < TOL and rel_err(host(sl), lad_o.reshape(shape[0], -1).sum(-1)) < 2e-5
+    back, _ = H.rqspline(s, dev(cw), dev(ch), dev(dv), tb, inverse=True)
+    assert rel_err(host(back), x) < 2e-5
+    ref = SplineActivation(shape[1:], n_bins=nb, tail_bound=tb).double()
+    with torch.no_grad():
+        ref.unnormalized_widths.copy_(torch.from_numpy(uw)); ref.unnormalized_heights.copy_(torch.from_numpy(uh))
+        ref.unnormalized_derivatives.copy_(torch.from_numpy(ud))
+    xc = torch.from_numpy(x).double().requires_grad_(True)
+    yc, lc = _spline_torch(ref, xc, inverse=False)
+    ((yc * torch.from_numpy(gy).double()).sum() + (lc * torch.from_numpy(gld).double()).sum()).backward()
+    layer = SplineActivation(shape[1:], n_bins=nb, tail_bound=tb)
+    layer.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    layer = layer.cuda()
+    assert layer._hip(dev(x))  # the library path, not the torch expressions
+    xg = dev(x).requires_grad_(True)
+    yg, lg = layer(xg)
+    assert rel_err(host(yg), yc.detach().numpy()) < TOL
+    ((yg * dev(gy)).sum() + (lg * dev(gld)).sum()).backward()
+    # (fp32 derivative arithmetic against a float64 truth: the log-derivative terms divide by bin widths, and sixteen random
+    # bins on [-8, 8] include some of a few hundredths)
+    assert rel_err(host(xg.grad), xc.grad.numpy()) < (5e-5 if nb <= 10 else 5e-4)
+    for (k, p), (_, q) in zip(layer.named_parameters(), ref.named_parameters()):
+        assert rel_err(host(p.grad), q.grad.numpy()) < (2e-4 if nb <= 10 else 2e-3), k
+
+
 def test_spline_tables_kernels(H, oracle):
     """knot tables and their way back on the library against the oracle's tables and autograd through this package's
     torch expressions of the same formulas"""
     from inf.layers.activations import spline_tables
     rng = np.random.default_rng(5)
-    for nb, tb in [(5, 10.0), (8, 3.0), (2, 1.5)]:
+    for nb, tb in [(5, 10.0), (8, 3.0), (2, 1.5), (10, 20.0), (16, 4.0)]:
         uw, uh, ud = rng.standard_normal(nb), rng.standard_normal(nb), rng.standard_normal(nb - 1)
         cw, ch, dv = H.rqspline_tables(dev(uw), dev(uh), dev(ud), tb)
         cw_o, ch_o, dv_o = oracle.spline_tables(uw, uh, ud, tb)

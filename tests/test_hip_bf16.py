@@ -85,7 +85,7 @@ def test_recon_term_in_bf16_storage(H):
     dx32, dw32, rl32 = H.backward(g.float(), z.float(), w, x=x.float(), recon_weight=0.5)
     assert same_bits(dx16, dx32.to(BF)) and same_bits(dw16, dw32)
     # (the loss is summed with one atomic per wave: the same value up to the order of the additions)
-    assert abs(float(rl16) - float(rl32)) <= 1e-6 * abs(float(rl32))
+    assert abs(float(rl16) - float(rl32)) <= 1e-5 * abs(float(rl32))
 
 
 def test_inverse_against_the_oracle_within_half_an_ulp(H, oracle):

@@ -219,3 +219,37 @@ def test_host_layers_keep_bf16_activations(H):
     sq = Squeeze()
     s, _ = sq(x16.detach())
     assert s.dtype == BF and same_bits(sq.reverse(s), x16.detach())
+
+
+def test_bf16_step_replays_as_a_graph(H):
+    """The bf16 entry points are stream-ordered and allocation-free like the f32 ones (the staging lives in the caller's
+    workspace): a captured inverse + backward replays on new inputs and returns what the eager calls return."""
+    torch.manual_seed(12)
+    B, C, HH, WW, K = 4, 64, 32, 32, 3
+    w = layer_weights(C, K, 5)
+    xs = [torch.randn(B, C, HH, WW, device="cuda").to(BF) for _ in range(2)]
+    gs = [torch.randn(B, C, HH, WW, device="cuda").to(BF) for _ in range(2)]
+    eager = []
+    for x, g in zip(xs, gs):
+        z = H.inverse(x, w)
+        dx, dw, _ = H.backward(g, z, w)
+        eager.append((z, dx, dw))
+    s = torch.cuda.Stream()
+    xin, gin = xs[0].clone(), gs[0].clone()
+    zg, dxg, dwg = torch.empty_like(xin), torch.empty_like(xin), torch.empty_like(w)
+    carry = H.new_carry(w)
+    with torch.cuda.stream(s):
+        H.inverse(xin, w, out=zg, carry=carry)
+        H.backward(gin, zg, w, dx_out=dxg, dw_out=dwg, carry=carry)
+        s.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            H.inverse(xin, w, out=zg, carry=carry)
+            H.backward(gin, zg, w, dx_out=dxg, dw_out=dwg, carry=carry)
+    for k in (1, 0, 1):
+        xin.copy_(xs[k])
+        gin.copy_(gs[k])
+        zg.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert same_bits(zg, eager[k][0]) and same_bits(dxg, eager[k][1]) and same_bits(dwg, eager[k][2]), k

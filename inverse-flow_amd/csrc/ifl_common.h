@@ -122,8 +122,9 @@ struct SplitState {
 size_t scan_duo_state_bytes();
 int scan_duo_max_images();
 bool scan_duo_supported(const Geom &g);
+// whole_image: an image of more than 16 rows stays in ONE workgroup, which sweeps its two tiles in turn (IFL_FLAG_WHOLE_IMAGE)
 int launch_scan_duo(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, int *flags,
-                    const float *wf32, unsigned *amax, void *state, hipStream_t s);
+                    const float *wf32, unsigned *amax, void *state, bool whole_image, hipStream_t s);
 // amax: optional device word that receives max|z| (atomicMax of float bits; must be cleared beforehand)
 // state: the caller's scan-state block or NULL; whole_image: keep one workgroup per image (IFL_FLAG_WHOLE_IMAGE)
 int launch_scan_mfma(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, int *flags,

@@ -1097,10 +1097,11 @@ int launch_scan_mfma(const float *x, const void *apack, float *z, const Geom &g,
     // an image of more than 16 rows is two workgroups, which needs the caller's scan-state block and a compute unit per
     // workgroup.  Everything else: one workgroup per image, below.
     if (scan_duo_supported(g)) {
-        if (nt == 1) return launch_scan_duo(x, apack, z, g, rh, rw, flags, wf32, amax, nullptr, s);
-        if (state && !whole_image && g.B <= scan_duo_max_images() && 2 * g.B <= device_cus()) {
+        if (nt == 1) return launch_scan_duo(x, apack, z, g, rh, rw, flags, wf32, amax, nullptr, false, s);
+        // (whole_image: the same two sweeps by one workgroup per image, bit-identical to the two-workgroup form)
+        if (state && g.B <= scan_duo_max_images() && (whole_image || 2 * g.B <= device_cus())) {
             if ((uintptr_t)state & 255) IFL_FAIL(IFL_EINVAL, "scan_state must be 256-byte aligned");
-            return launch_scan_duo(x, apack, z, g, rh, rw, flags, wf32, amax, state, s);
+            return launch_scan_duo(x, apack, z, g, rh, rw, flags, wf32, amax, state, whole_image, s);
         }
     }
 #define IFL_CASE(CC, KK, NN) \

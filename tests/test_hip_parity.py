@@ -443,8 +443,10 @@ def test_split_scan_streams_and_graph_replay(H):
 
 def test_scan_state_is_caller_owned(H):
     """The two-workgroup scan runs only on a block the caller passes (scan_state: the library never allocates and keeps no
-    registry); without one, or with IFL_FLAG_WHOLE_IMAGE, one workgroup per image computes the same bits; a block that is
-    not 256-byte aligned is refused; z aliasing x is refused."""
+    registry).  With IFL_FLAG_WHOLE_IMAGE one workgroup per image sweeps the same two tiles through the same mailbox and
+    computes the same bits; without a block the round-1 whole-image kernel runs (its own summation order: the same
+    result within the tolerance against the exact solver, not bit for bit); a block that is not 256-byte aligned is
+    refused; z aliasing x is refused."""
     torch.manual_seed(9)
     B, C, Hh, Ww, K = 8, 64, 32, 32, 3
     w = torch.nn.init.dirac_(torch.empty(C, C, K, K)) + 0.02 * torch.randn(C, C, K, K)
@@ -461,7 +463,8 @@ def test_scan_state_is_caller_owned(H):
     assert L.ifl_inverse_f32(x.data_ptr(), w.data_ptr(), z_none.data_ptr(), B, C, Hh, Ww, K, K, 0, 0, ws.data_ptr(), nb, None,
                              None, stream) == 0
     z_whole = H.inverse(x, w, "TL", H.FLAG_WHOLE_IMAGE)
-    assert torch.equal(z_split, z_none) and torch.equal(z_split, z_whole)
+    assert torch.equal(z_split, z_whole)
+    assert float((z_split - z_none).norm() / z_split.norm()) < 2e-6
     own = torch.zeros(L.ifl_scan_state_bytes() + 256, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
     off = (-own.data_ptr()) % 256

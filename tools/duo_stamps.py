@@ -32,5 +32,5 @@ for part, name in ((0, "upper / single"), (1, "lower")):
              o[3] / max((o[2] - o[1]) * 10.0, 1.0)))
     print("   chain wave 0: %d cycles per step at the barrier" % (o[5] // max(steps, 1)))
     print("   helper 0: slow polls %d (spins %d), gate wait %.2f us" % (o[8], o[9], o[10] / 100.0))
-    names = ["barrier", "LDS requests", "dma issue", "LDS wait", "hand-off in + z product", "stores + staging", "final wait"]
+    names = ["barrier", "products 1", "z, requests", "memory requests", "hand-off in, seeds", "products 2", "final wait"]
     print("   helper 0 cycles per step:", {n: o[16 + k] // max(steps, 1) for k, n in enumerate(names)})

@@ -72,8 +72,8 @@ template <int C, int KH, int KW> struct DuoCfg {
     static constexpr int CPH = NCH / NW;   // chunks of a row that one helper moves (its own 16 channels)
     static_assert(CPH == 2, "a helper's 16 channels are two chunks");
     static constexpr int PF = 8;           // a row is requested PF steps before its first pixel
-    static constexpr int LEAD = 4;         // steps before the first pixel of a tile that takes no hand-off (its first rows: one burst)
-    static constexpr int ZLAG = 3;         // z of diagonal d - ZLAG goes into the tile in step d (formed at the end of step d - 1 on the carried fragments)
+    static constexpr int LEAD = 1;         // steps before the first pixel of a tile that takes no hand-off (its first row is waited for there)
+    static constexpr int ZLAG = 2;         // z of diagonal d - ZLAG goes into the tile in step d (formed at the end of step d - 1)
     static constexpr int SLAG = ZLAG + 32; // row r leaves in step r + SLAG (one step after its last z went into the tile)
 #ifndef IFL_PFH
 #define IFL_PFH 2
@@ -85,22 +85,37 @@ template <int C, int KH, int KW> struct DuoCfg {
     static constexpr int GATE = IFL_GATE;  // the lower part asks for its first line once the upper part's diagonal 14 + GATE is visible
     static_assert(PFH < NHL && PF >= PFH + 2, "the sweep's lead-in covers both prefetches");
     // which wave multiplies tap (dh, dw): by the number of diagonals it reaches back
-    static constexpr bool chain_tap(int dh, int dw) { return dh + dw >= 1 && dh + dw <= 2; }
-    static constexpr bool helper_tap(int dh, int dw) { return dh + dw >= 3; }
-    static constexpr bool HAS_HT = KH + KW - 2 >= 3; // the helper contributes partial sums (3x3); 2x2: the seed is x itself
+    // which wave multiplies tap (dh, dw).  IFL_SPLIT_TAPS (an experiment that is kept compilable): the taps three and four
+    // diagonals back go to the helper, which hands their sums over as a seed written over x in the tile.  Measured: the
+    // helper's products then contend with the chain's for the matrix pipe at the wrong moments; the step got longer.
+#ifndef IFL_SPLIT_TAPS
+#define IFL_SPLIT_TAPS 0
+#endif
+    static constexpr bool chain_tap(int dh, int dw) { return dh + dw >= 1 && (!IFL_SPLIT_TAPS || dh + dw <= 2); }
+    static constexpr bool helper_tap(int dh, int dw) { return IFL_SPLIT_TAPS && dh + dw >= 3; }
+    static constexpr bool HAS_HT = IFL_SPLIT_TAPS && KH + KW - 2 >= 3; // the helper contributes partial sums
 };
 
+#define IFL_STR2(x) #x
+#define IFL_STR(x) IFL_STR2(x)
+#ifndef IFL_LOWER_SLEEP
+#define IFL_LOWER_SLEEP 127 // x 64 cycles: what a lower part waits before it requests its rows
+#endif
+#ifndef IFL_A_VS
+#define IFL_A_VS 4
+#endif
+#ifndef IFL_WEAVE
+#define IFL_WEAVE 4 // instructions of the chain's epilogue per trailing MFMA
+#endif
 #ifndef IFL_PRIO_CHAIN
 #define IFL_PRIO_CHAIN 2
 #endif
 #ifndef IFL_PRIO_HELPER
 #define IFL_PRIO_HELPER 0
 #endif
-#define IFL_STR2(x) #x
-#define IFL_STR(x) IFL_STR2(x)
 // Development aid (tools/exp_scan.sh, tools/time_scan.py): what-if builds that drop one kind of work (results are then
 // garbage) to see what a step is waiting for.  1: no seed update, 2: no z write, 4: no helper products, 8: no seed read
-// (chain), 16: no helper fragment reads, 32: no trailing products (chain), 64: no row loads / stores, 128: no ring write.
+// (chain), 16: no helper fragment reads, 32: no trailing products (chain), 64: no row loads, 128: no ring write, 256: no row stores.
 // Any bit forces the verdict good.  Never defined in the product.
 #ifndef IFL_EXP
 #define IFL_EXP 0
@@ -149,9 +164,22 @@ __device__ __forceinline__ void dma_piece(unsigned lds_dst, unsigned voff, const
 {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(voff), "s"(src) : "memory", "m0");
 }
+// Cache policy of the z rows: 0 default, 1 nt, 2 sc1, 3 sc0 sc1.  With the default policy the 33.5 MB of z that a launch
+// writes in its last third sit dirty in the L2s when it ends and the launch is not over before they are written back
+// (+4 us measured); written through (sc1) they leave while the sweep is still running.  The weight-gradient kernel that
+// reads z next takes the same time either way.
+#ifndef IFL_ST_POL
+#define IFL_ST_POL 2
+#endif
+#define IFL_POL_0
+#define IFL_POL_1 nt
+#define IFL_POL_2 sc1
+#define IFL_POL_3 sc0 sc1
+#define IFL_CAT2(a, b) a##b
+#define IFL_CAT(a, b) IFL_CAT2(a, b)
 __device__ __forceinline__ void store_piece(unsigned voff, const floatx4 &v, char *dst)
 {
-    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(dst) : "memory");
+    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 " IFL_STR(IFL_CAT(IFL_POL_, IFL_ST_POL)) "\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(dst) : "memory");
 }
 
 template <int C, int KH, int KW, bool PAD>
@@ -169,6 +197,9 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
     static_assert(!PAD, "the duo scan takes layers of exactly 32 or 64 channels (launch_scan_mfma routes the others)");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
+#ifdef IFL_PAD
+    asm volatile(".rept " IFL_STR(IFL_PAD) "\n\ts_nop 0\n\t.endr"); // (development aid: shifts the code behind it by 4 IFL_PAD bytes)
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool is_chain = wave < NW;
@@ -218,12 +249,37 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
     const unsigned tbase = ldsbase + Cfg::OFF_T + n * Cfg::TROWB + (2 * wv + (g >> 1)) * 1024 + (g & 1) * 512;
     const int tq4 = 4 * (g & 1);
     const unsigned tidle = tbase + (lane & 31) * 4; // what a lane without a pixel reads: a word of its own bank
+    // the same address in two instructions: byte (4 wp + 64 (g & 1)) mod 128 of the lane's 128 bytes, wp = the stored column
+    // of logical column t - n (reflected or not): (crel + srel t) mod 128 with a per-lane constant
+    const int crel = rw ? 4 * (31 + n) + 64 * (g & 1) : 64 * (g & 1) - 4 * n;
+    const int srel = rw ? -4 : 4;
     int Ws = W;
     asm volatile("" : "+s"(Ws));
-    auto taddr = [&](const int w) { // tile address of (row n, channels c0.., logical column w), 0 <= w < 32
+    [[maybe_unused]] auto taddr = [&](const int w) { // tile address of (row n, channels c0.., logical column w), 0 <= w < 32
         const int wp = rw ? 31 - w : w;
         return tbase + ((((wp >> 2) + tq4) & 7) << 4) + ((wp & 3) << 2);
     };
+    // ---- the tile's rows move as whole 1-KiB pieces: the two chunks of a wave's own 16 channels (helper w and chain wave w share
+    //      them).  Lane l of a piece holds the sixteen bytes at LDS position l: channel cc = l >> 3 of the chunk, quad
+    //      ((l & 7) - 4 (cc >> 2)) & 7 of its line: 8 consecutive lanes cover one 128-byte (channel, row) line, loads and stores
+    const int pcc = lane >> 3, pq = ((lane & 7) - 4 * (pcc >> 2)) & 7;
+    const unsigned pgo = (unsigned)(pcc * H * W * 4 + pq * 16); // byte offset inside a chunk's 8 channel planes
+    const char *xg = (const char *)xin + ((size_t)b * C + 16 * wv) * H * W * sizeof(float);
+    const unsigned chunkB = (unsigned)(8 * H * W * 4);
+    const unsigned tchunk = ldsbase + Cfg::OFF_T + (2 * wv) * 1024; // (+ row TROWB, + 1024 for the second chunk)
+    // rows [r0, r1) of the tile at image row hoff, this wave's two pieces each: global -> tile (rows may be reflected)
+    auto load_rows = [&](const int hoff, const int r0, const int r1) {
+        for (int r = r0; r < r1; ++r) {
+            const char *src = xg + (rh ? H - 1 - (hoff + r) : hoff + r) * W * 4;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(tchunk + r * Cfg::TROWB);
+            dma_piece(dst, pgo, src);
+            dma_piece(dst + 1024, pgo + chunkB, src);
+        }
+    };
+    // The launched tile's rows are requested at kernel entry, in front of everything else: the latency of the first rows
+    // overlaps the weight loads.  The helper takes the rows it will wait for one by one, [0, HSPLIT); the chain wave of the
+    // same channels takes the rest and waits for all of them at once, two steps before the first of them is due.
+    constexpr int HSPLIT = 8;
 
 #ifdef IFL_STAMPS
     unsigned long long st_rt[4] = {__builtin_amdgcn_s_memrealtime(), 0, 0, 0}, st_mt[2] = {0, 0}, st_bar = 0;
@@ -259,6 +315,11 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
 
     if (is_chain) {
         // =================================== chain waves ===================================================
+        if (!(IFL_EXP & 64)) {
+            const Sweep s0 = sweep_of(0, 0);
+            if (my_part == 1) __builtin_amdgcn_s_sleep(IFL_LOWER_SLEEP);
+            load_rows(s0.hoff, HSPLIT, s0.Hp);
+        }
         half8 A[NS - 1][NQ][2]; // this wave's folded taps as A fragments (hi, lo), in registers for the whole kernel
         {
             half8 Aload[NS - 1][NQ][2]; // all loads first, then the pins (a pin behind its load serialises the round trips)
@@ -278,8 +339,12 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
 #pragma unroll
                         for (int hl = 0; hl < 2; ++hl) {
                             A[s][q][hl] = Aload[s][q][hl];
-                            // (pinned, or hipcc re-loads the weights inside the loop; an MFMA reads them from the accumulator half)
-                            asm volatile("" : "+a"(A[s][q][hl]));
+                            // (pinned, or hipcc re-loads the weights inside the loop.  An MFMA reads them from the accumulator half
+                            // of the register file, which holds 128 registers per lane at two waves per SIMD and the accumulators as
+                            // well: the low parts of the first IFL_A_VS taps stay in ordinary registers -- left to itself the
+                            // compiler parks them there anyway and copies them into scratch registers in front of every use)
+                            if (NW == 4 && hl == 1 && s < IFL_A_VS) asm volatile("" : "+v"(A[s][q][hl]));
+                            else asm volatile("" : "+a"(A[s][q][hl]));
                         }
         }
         const int wadr = RBB + (((c0 / 32) * 2) * 4 + (c0 % 32) / 8) * 256 + n * 16 + ((c0 % 8) / 4) * 8;
@@ -290,43 +355,75 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
             const bool hval = n < Hp;
             const int ND = Hp + W - 1;       // diagonals 0 .. ND-1
             const int DEND = ND + SLAG - 32; // the helpers' last step (the last row leaves)
-            floatx4 ahi[2], amid[2];         // [P]: diagonal d of a step of parity P; [P ^ 1]: diagonal d+1
+            // Rolling accumulators ("push" form): the accumulator of diagonal t is [(t + 1) mod 3]; the step loop is unrolled by
+            // three, so that every step names its accumulators at compile time (no register copies when they rotate)
+            floatx4 ahi[3], amid[3];
+            half8 F2h[NQ], F2l[NQ]; // fragments of the source rows two up, carried to the next step
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < 3; ++k) {
                 ahi[k] = floatx4{0.f, 0.f, 0.f, 0.f};
                 amid[k] = floatx4{0.f, 0.f, 0.f, 0.f};
             }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    F2h[q][j] = (_Float16)0.f;
+                    F2l[q][j] = (_Float16)0.f;
+                }
 
-            auto step = [&](auto p_c, const int d) {
-                constexpr int P = decltype(p_c)::value;
-                constexpr int NSEED = (IFL_EXP & 8) ? 0 : 2; // LDS operations of the seed read
-                constexpr int srcoff = (P ^ 1) * SLOTB; // ring slot of diagonal d-1 (P = d & 1)
-                constexpr int dstoff = P * SLOTB;       // ring slot of diagonal d
-                // r of diagonal d-1 complete in the ring (this wave's ring writes drained: lgkmcnt), seeds of diagonal d in the tile
+            auto step = [&](auto r_c, const int d) {
+                constexpr int R = decltype(r_c)::value; // (d + 1) mod 3
+                constexpr int A0 = R, A1 = (R + 1) % 3, A2 = (R + 2) % 3; // accumulators of the diagonals d, d+1, d+2
+                constexpr int NDH = KH < 2 ? KH : 2;
+                constexpr int NREQ = 2 + NDH * PER;
+                constexpr int NRD2 = KH > 2 ? PER : 0;
+                const int srcoff = ((d + 1) & 1) * SLOTB; // ring slot of diagonal d-1
+                const int dstoff = (d & 1) * SLOTB;       // ring slot of diagonal d
+                // r of diagonal d-1 complete in the ring (this wave's ring writes drained: lgkmcnt), x of this step in the tile
 #ifdef IFL_STAMPS
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
 #endif
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #ifdef IFL_STAMPS
-                st_bar += __builtin_amdgcn_s_memtime() - tb0;
+                {
+                    const unsigned long long tb1 = __builtin_amdgcn_s_memtime();
+                    st_bar += tb1 - tb0;
+                    // per-step timeline of image 0: when this wave passed barrier d, and how long it had waited there
+                    if (g_stamps && b == 0 && tid == 0 && d - sw.dfirst < 64) {
+                        g_stamps[128 + (my_part == 1 ? 128 : 0) + 2 * (d - sw.dfirst)] = tb1;
+                        g_stamps[128 + (my_part == 1 ? 128 : 0) + 2 * (d - sw.dfirst) + 1] = tb1 - tb0;
+                    }
+                }
 #endif
-                floatx2 xq[2] = {floatx2{0.f, 0.f}, floatx2{0.f, 0.f}};
-                half8 Fh[KH][NQ], Fl[KH][NQ];
-                // (the fragments first -- LDS operations of a wave complete in order -- the seed is needed last; the slot is part of
-                // the instruction's offset field: no address arithmetic in front of the requests)
+                // (the fragments requested during the previous step have landed: see `landed`)
 #pragma unroll
-                for (int dh = 0; dh < KH; ++dh) lds_read_set<NQ, srcoff>(Fh[dh], Fl[dh], radr[dh]);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int q = 0; q < NQ; ++q) asm volatile("" : "+v"(F2h[q]), "+v"(F2l[q]));
                 const int w0 = d - n;
                 const bool valid = hval && (unsigned)w0 < (unsigned)Ws;
-                unsigned xa = taddr(w0); // (computed for every lane, then selected: no branch; a lane without a pixel reads a word of its own bank)
-                asm volatile("" : "+v"(xa));
-                xa = valid ? xa : tidle;
-                if (!(IFL_EXP & 8)) tile_read4(xq[0], xq[1], xa);
+                // (a lane without a pixel reads a word of its own bank)
+                const unsigned xa = valid ? tbase + ((crel + srel * d) & 127) : tidle;
+                floatx2 xq[2];
+                half8 Fh[2][NQ], Fl[2][NQ];
+                auto request = [&](int j) {
+                    int c = 0;
+                    if (c++ == j) asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:32" : "=v"(xq[0]) : "v"(xa));
+                    if (c++ == j) asm volatile("ds_read2_b32 %0, %1 offset0:64 offset1:96" : "=v"(xq[1]) : "v"(xa));
+#pragma unroll
+                    for (int dh = 0; dh < NDH; ++dh) {
+                        const unsigned fa = radr[dh] + srcoff;
+                        if (c++ == j) lds_read_b128_o<0>(Fh[dh][0], fa);
+                        if (c++ == j) lds_read_b128_o<4 * 256>(Fl[dh][0], fa);
+                        if constexpr (NQ == 2) {
+                            if (c++ == j) lds_read_b128_o<8 * 256>(Fh[dh][1], fa);
+                            if (c++ == j) lds_read_b128_o<12 * 256>(Fl[dh][1], fa);
+                        }
+                    }
+                };
                 __builtin_amdgcn_sched_barrier(0);
                 // The destination of an asynchronous LDS read must stay allocated until the wait that covers it: as an operand of
-                // this statement behind the wait it does.  (A destination nothing reads later -- the last step's fragments for the
+                // this statement behind the wait it does.  (A destination nothing reads later -- the last step's fragments for
                 // taps that feed a diagonal beyond the image -- is otherwise handed out again at once, and the data that lands
                 // later goes on top of whatever lives there by then: tests/test_build_checks.py walks the ISA for exactly that.)
                 auto landed = [&](int dh) {
@@ -334,51 +431,98 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                     for (int q = 0; q < NQ; ++q) asm volatile("" : "+v"(Fh[dh][q]), "+v"(Fl[dh][q]));
                 };
                 // A(t) x {hi, lo} fragments -> accumulator tgt (order: per k-step hi.hi and hi.lo, then the lo.hi products)
-                auto mf = [&](int dh, int dw, int tgt, bool init) {
-                    const int t = dh * KW + dw;
+                auto mf_one = [&](int t, const half8 *fh, const half8 *fl, int tgt, int k, bool init = false) {
+                    int c = 0;
                     const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
-                        ahi[tgt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], Fh[dh][q], (init && q == 0) ? zero : ahi[tgt], 0, 0, 0);
-                        amid[tgt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], Fl[dh][q], (init && q == 0) ? zero : amid[tgt], 0, 0, 0);
+                        if (c++ == k)
+                            ahi[tgt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], fh[q], (init && q == 0) ? zero : ahi[tgt], 0, 0, 0);
+                        if (c++ == k)
+                            amid[tgt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][0], fl[q], (init && q == 0) ? zero : amid[tgt], 0, 0, 0);
                     }
 #pragma unroll
                     for (int q = 0; q < NQ; ++q)
-                        amid[tgt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][1], Fh[dh][q], amid[tgt], 0, 0, 0);
+                        if (c++ == k) amid[tgt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[t - 1][q][1], fh[q], amid[tgt], 0, 0, 0);
                 };
-                // ---- critical: the taps one diagonal back -> diagonal d (LDS operations of a wave complete in order)
+                auto mf = [&](int t, const half8 *fh, const half8 *fl, int tgt, bool init = false) {
+#pragma unroll
+                    for (int k = 0; k < GM; ++k) mf_one(t, fh, fl, tgt, k, init);
+                };
+                auto fence = [&]() { __builtin_amdgcn_sched_barrier(0); };
+
+                // ---- leading: taps (2, dw) of r_{d-2} (fragments kept from the previous step) -> diagonals d + dw; they
+                //      fill the matrix pipe while this step's LDS requests (one behind each MFMA) are in flight
+                if constexpr (KH > 2) {
+                    constexpr int NLEADM = (KW > 1 ? 2 : 1) * GM;
+                    constexpr int RPM = (NREQ + NLEADM - 1) / NLEADM;
+#pragma unroll
+                    for (int k = 0; k < NLEADM; ++k) {
+                        if (k < GM) mf_one(2 * KW + 0, F2h, F2l, A0, k);
+                        else mf_one(2 * KW + 1, F2h, F2l, A1, k - GM);
+                        // (MFMAs are pure: tie the result to an opaque statement, or they sink below the requests)
+                        asm volatile("" : "+a"(ahi[k < GM ? A0 : A1]), "+a"(amid[k < GM ? A0 : A1]));
+                        fence();
+#pragma unroll
+                        for (int j = k * RPM; j < (k + 1) * RPM && j < NREQ; ++j) request(j);
+                        fence();
+                    }
+                    if constexpr (KW > 2) mf(2 * KW + 2, F2h, F2l, A2, true); // first contribution to diagonal d+2
+                    fence();
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NREQ; ++j) request(j);
+                    fence();
+                }
+                // ---- critical: taps (0,1) and (1,0) of r_{d-1} -> diagonal d.  The dh=2 fragments of r_{d-1} (next
+                //      step's leading operands; every MFMA that reads the old ones has been issued) ride behind the first
+                auto request2 = [&](int j) {
+                    int c = 0;
+                    const unsigned fa = radr[KH > 2 ? 2 : 0] + srcoff;
+                    if (c++ == j) lds_read_b128_o<0>(F2h[0], fa);
+                    if (c++ == j) lds_read_b128_o<4 * 256>(F2l[0], fa);
+                    if constexpr (NQ == 2) {
+                        if (c++ == j) lds_read_b128_o<8 * 256>(F2h[1], fa);
+                        if (c++ == j) lds_read_b128_o<12 * 256>(F2l[1], fa);
+                    }
+                };
                 if constexpr (KW > 1) {
-                    lgkm_wait_n((KH - 1) * PER + NSEED); // the dh=0 fragments have landed
+                    lgkm_wait_n((NDH - 1) * PER); // x and the dh=0 fragments have landed
+                    asm volatile("" : "+v"(xq[0]), "+v"(xq[1]));
                     landed(0);
-                    mf(0, 1, P, false);
-                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < GM; ++k) {
+                        mf_one(1, Fh[0], Fl[0], A0, k);
+                        if constexpr (KH > 2) {
+                            asm volatile("" : "+a"(ahi[A0]), "+a"(amid[A0]));
+                            fence();
+                            if (k < PER) request2(k);
+                            fence();
+                        }
+                    }
+                    fence();
                 }
                 if constexpr (KH > 1) {
-                    lgkm_wait_n((KH - 2) * PER + NSEED); // ... and the dh=1 fragments
+                    lgkm_wait_n(NRD2); // ... and the dh=1 fragments
                     landed(1);
-                    mf(1, 0, P, false);
-                    __builtin_amdgcn_sched_barrier(0);
+                    mf(KW, Fh[1], Fl[1], A0);
+                    fence();
                 }
-                lgkm_wait_n(0); // (the dh=2 fragments and the seed: requested 12 MFMAs ago)
+                // ---- trailing: the remaining taps of r_{d-1} (targets d+1, d+2) with the chain's epilogue woven in
+                const floatx4 head_hi = ahi[A0], head_mid = amid[A0];
 #pragma unroll
-                for (int dh = 0; dh < KH; ++dh) landed(dh);
-                asm volatile("" : "+v"(xq[0]), "+v"(xq[1]));
-                // ---- trailing: the taps two diagonals back -> diagonal d+1, with the chain's epilogue woven in
-                const floatx4 head_hi = ahi[P], head_mid = amid[P];
-                int ntr = 0;
-#pragma unroll
-                for (int dh = 0; dh < KH; ++dh)
+                for (int dh = 0; dh < NDH; ++dh)
 #pragma unroll
                     for (int dw = 0; dw < KW; ++dw)
-                        if (dh + dw == 2 && !(IFL_EXP & 32)) mf(dh, dw, P ^ 1, ntr++ == 0);
-                // epilogue: r_d = seed + acc -> split fp16 -> ring (lanes outside the image write to the dump: no branch)
+                        if (dh + dw >= 2) {
+                            // (without a dh=2 row the farthest tap is this one: it opens its diagonal)
+                            mf(dh * KW + dw, Fh[dh], Fl[dh], dh + dw == 2 ? A1 : A2, KH < 3 && dh + dw == KH + KW - 2);
+                        }
+                // epilogue: r_d = x + acc -> split fp16 -> ring (lanes outside the image write to the dump: no branch)
                 {
                     float rv[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float sd = Cfg::HAS_HT ? xq[r >> 1][r & 1] : xq[r >> 1][r & 1] * xscale; // (3x3: the helper scaled it)
-                        rv[r] = sd + head_hi[r] + head_mid[r] * LO_INV;
-                    }
+                    for (int r = 0; r < 4; ++r) rv[r] = xq[r >> 1][r & 1] * xscale + head_hi[r] + head_mid[r] * LO_INV;
                     half4 hi, lo;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -390,33 +534,41 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                     *(half4 *)rp = hi;
                     *(half4 *)(rp + 4 * 256) = lo;
                     const float m = fmaxf(fmaxf(fabsf(rv[0]), fabsf(rv[1])), fmaxf(fabsf(rv[2]), fabsf(rv[3])));
-                    rmax = valid ? fmaxf(rmax, m) : rmax;
+                    rmax = fmaxf(rmax, valid ? m : 0.f);
                 }
-                // scheduling pattern for the region since the last fence: 2 MFMAs, then NM x (1 MFMA, 3 others)
-                constexpr int NTR = GM * ((KW > 2 ? 1 : 0) + (KH > 1 && KW > 1 ? 1 : 0) + (KH > 2 ? 1 : 0));
-                if constexpr (NTR > 4 && !(IFL_EXP & 32)) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 3);
+                // scheduling pattern for the region since the last fence: 1 MFMA, then (1 MFMA, IFL_WEAVE others) until the others
+                // run out -- the ring write goes out several MFMAs before the step's last one, whose time covers its latency
+                constexpr int NTR = GM * (KH * KW - 1 - (KW > 1 ? 1 : 0) - (KH > 1 ? 1 : 0) - (KH > 2 ? KW : 0));
+                static_assert(NTR >= 0, "trailing taps");
+                if constexpr (NTR > 4) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 3);
 #pragma unroll
-                    for (int k = 0; k < NTR - 2; ++k) {
+                    for (int k = 0; k < NTR - 1; ++k) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 3);
-                        __builtin_amdgcn_sched_group_barrier(0x296, 3, 3); // VALU | SALU | VMEM | DS
+                        __builtin_amdgcn_sched_group_barrier(0x296, IFL_WEAVE, 3); // VALU | SALU | VMEM | DS
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
 
             // steps dfirst .. DEND, one barrier each (the helpers mirror them); the chain works in steps -1 .. ND-1
-            // (step -1: r_{-2} of a lower tile -- rows 14, 15 of the part above -- reaches diagonal 0 through tap (2,0))
+            // (step -1: r_{-2} of a lower tile -- rows 14, 15 of the part above -- becomes next step's fragments two rows up)
             int d = sw.dfirst;
             for (; d < -1; ++d) asm volatile("s_barrier" ::: "memory");
-            for (; d + 1 <= ND - 1; d += 2) { // (d = -1: odd)
-                step(std::integral_constant<int, 1>{}, d);
-                step(std::integral_constant<int, 0>{}, d + 1);
+            for (; d + 2 <= ND - 1; d += 3) { // ((d + 1) mod 3 = 0 here)
+                // (the rows this wave requested at kernel entry -- HSPLIT and up -- have landed: the only vector-memory operations
+                // it has in flight; two steps and a barrier before anybody touches the first of them)
+                if (d == HSPLIT - 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                step(std::integral_constant<int, 0>{}, d);
+                step(std::integral_constant<int, 1>{}, d + 1);
+                step(std::integral_constant<int, 2>{}, d + 2);
             }
-            if (d <= ND - 1) {
-                step(std::integral_constant<int, 1>{}, d);
-                ++d;
-            }
+            if (d <= ND - 1) step(std::integral_constant<int, 0>{}, d++);
+            if (d <= ND - 1) step(std::integral_constant<int, 1>{}, d++);
+            // (the last step's fragment requests for a diagonal that does not exist are covered by this wait)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) asm volatile("" : "+v"(F2h[q]), "+v"(F2l[q]));
             for (; d <= DEND; ++d) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         };
 
@@ -471,42 +623,18 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
 
     // ======================================= helper waves ==================================================
     {
-        // this wave's taps with slack (three and four diagonals back) and L^-1 (slot NS-1) as A fragments
-        half8 A[NS][NQ][2];
-        {
-            half8 Aload[NS][NQ][2];
+        half8 Z[NQ][2]; // L^-1 as A fragments (slot NS-1 of the packed weights)
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
-                if (s == NS - 1 || Cfg::helper_tap((s + 1) / KW, (s + 1) % KW))
+        for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q)
+            for (int hl = 0; hl < 2; ++hl) Z[q][hl] = apack[((((size_t)wv * NS + (NS - 1)) * NQ + q) * 2 + hl) * 64 + lane];
+        // (used here, so that the compiler's wait for these loads sits here and not -- as vmcnt(0) -- inside the step loop,
+        // where it would drain the DMAs and stores in flight)
 #pragma unroll
-                        for (int hl = 0; hl < 2; ++hl)
-                            Aload[s][q][hl] = apack[((((size_t)wv * NS + s) * NQ + q) * 2 + hl) * 64 + lane];
-            // (used here, so that the compiler's wait for these loads sits here and not -- as vmcnt(0) -- inside the step loop,
-            // where it would drain the DMAs and stores in flight)
+        for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
-                if (s == NS - 1 || Cfg::helper_tap((s + 1) / KW, (s + 1) % KW))
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                        for (int hl = 0; hl < 2; ++hl) {
-                            A[s][q][hl] = Aload[s][q][hl];
-                            asm volatile("" : "+v"(A[s][q][hl])); // (ordinary registers: the carried fragment sets fill the accumulator half)
-                        }
-        }
-        // which fragment sets (dh) this wave's products read: dh = 0 (z) and the rows of its taps
-        constexpr bool NEED1 = Cfg::HAS_HT && KH > 1, NEED2 = Cfg::HAS_HT && KH > 2;
-        // ---- the tile's rows: this wave moves the two chunks of its own 16 channels, as whole 1-KiB pieces ------------------
-        // lane l of a piece holds the sixteen bytes at LDS position l: channel cc = l >> 3 of the chunk, quad
-        // ((l & 7) - 4 (cc >> 2)) & 7 of its line: 8 consecutive lanes cover one 128-byte (channel, row) line, loads and stores
-        const int pcc = lane >> 3, pq = ((lane & 7) - 4 * (pcc >> 2)) & 7;
-        const unsigned pgo = (unsigned)(pcc * H * W * 4 + pq * 16); // byte offset inside a chunk's 8 channel planes
-        const char *xg = (const char *)xin + ((size_t)b * C + 16 * wv) * H * W * sizeof(float);
+            for (int hl = 0; hl < 2; ++hl) asm volatile("" : "+v"(Z[q][hl]));
         char *zg = (char *)zout + ((size_t)b * C + 16 * wv) * H * W * sizeof(float);
-        const unsigned chunkB = (unsigned)(8 * H * W * 4);
-        const unsigned tchunk = ldsbase + Cfg::OFF_T + (2 * wv) * 1024; // (+ row TROWB, + 1024 for the second chunk)
         const unsigned dmy = __builtin_amdgcn_readfirstlane(ldsbase + Cfg::OFF_DMY);
         const unsigned hdump = ldsbase + Cfg::OFF_DUMP + 2048 + lane * 4;
         // mailbox role of helper 0: lane l carries the 8-byte piece (row 14 + (l & 1), plane (l >> 1) & 15, half l >> 5)
@@ -528,17 +656,26 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
     do {              \
     } while (0)
 #endif
-        // "all but the n youngest vector-memory operations are complete" for a run-time n (an immediate in the instruction): n
-        // rounded DOWN to a multiple of four -- a few operations more are waited for, the rows of the next step or two,
-        // requested six steps ago -- keeps the dispatch short.  The counts that occur are at most CPH (PF - 2) + PF - 2 = 18.
+        // "all but the n youngest vector-memory operations are complete" for a run-time n (an immediate in the instruction):
+        // exact up to 3, above that rounded DOWN to a multiple of four (a few operations more are waited for: rows further
+        // down the tile, requested at the same time) -- a short dispatch.  The counter holds 63.
         auto wait_vm = [&](int n) {
-            switch (n >> 2) {
-            case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-            case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            if (n < 4) {
+                switch (n) {
+                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                }
+                return;
             }
+#define IFL_V(N) \
+    case N / 4: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+            switch (n >> 2) {
+                IFL_V(4) IFL_V(8) IFL_V(12) IFL_V(16) IFL_V(20) IFL_V(24) IFL_V(28) IFL_V(32) IFL_V(36) IFL_V(40) IFL_V(44) IFL_V(48)
+            default: asm volatile("s_waitcnt vmcnt(52)" ::: "memory"); break;
+            }
+#undef IFL_V
         };
         auto reduce_amax = [&]() {
             if (amax) {
@@ -558,9 +695,17 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
             if (tid == NW * 64) sp.gen[b] = gen0 >= 0xFFFFFFF0u ? 0u : gen0 + 2;
         };
 
-        auto helper_sweep = [&](const Sweep &sw, const bool last_of_pass) {
+        if (!(IFL_EXP & 64)) {
+            const Sweep s0 = sweep_of(0, 0);
+            // (a lower part's first pixel is sixteen steps away: it stays out of the way of the upper parts' requests, which
+            // every compute unit of the chip issues at this very moment)
+            if (my_part == 1) __builtin_amdgcn_s_sleep(IFL_LOWER_SLEEP);
+            load_rows(s0.hoff, 0, s0.Hp < HSPLIT ? s0.Hp : HSPLIT);
+        }
+
+        auto helper_sweep = [&](const Sweep &sw, const bool last_of_pass, const bool preloaded) {
             const int Hp = sw.Hp, hoff = sw.hoff;
-            const float xscale = sw.xscale, zscale = sw.zscale;
+            const float zscale = sw.zscale;
             const unsigned tag = sw.tag;
             const int dfirst = sw.dfirst;
             const int ND = Hp + W - 1;
@@ -595,110 +740,52 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                     __builtin_amdgcn_s_sleep(2);
                 }
             };
-            // a row's two pieces of this wave: global -> tile
-            auto load_row = [&](const int r) {
-                const char *src = xg + row_off(r);
-                const unsigned dst = __builtin_amdgcn_readfirstlane(tchunk + r * Cfg::TROWB);
-                dma_piece(dst, pgo, src);
-                dma_piece(dst + 1024, pgo + chunkB, src);
-            };
+            // All rows of the tile are requested at once, in row order, before the sweep's first step (the launched tile's: at
+            // kernel entry, see below): the requests cost the helper its issue slots while nothing else is going on, and a row is
+            // waited for one step before its first pixel.
+            if (!preloaded && !(IFL_EXP & 64)) load_rows(hoff, 0, Hp);
+            const int HR = preloaded ? (Hp < HSPLIT ? Hp : HSPLIT) : Hp; // the rows this wave requested
 
             // Every per-step condition is a range of d: one unsigned compare each, "(unsigned)(d - lo) < n" with n = 0
             // when the sweep does not have that duty (the conditions are wave-uniform)
             const unsigned n_hin = mb_in ? (unsigned)(dl_last + 3) : 0u;   // d in [-2, dl_last]
             const unsigned n_hout = mb_out ? (unsigned)(u_last - 13) : 0u; // d - 1 in [14, u_last]
 
-            half8 Fh[2][KH][NQ], Fl[2][KH][NQ]; // [P]: fragments of r_{d-1}, requested in a step of parity P, used in the next one
-            floatx4 hhi[2], hmid[2];             // [P]: this wave's partial sums of diagonal d+1; [P ^ 1]: of diagonal d+2
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                hhi[k] = floatx4{0.f, 0.f, 0.f, 0.f};
-                hmid[k] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int dh = 0; dh < KH; ++dh)
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            Fh[k][dh][q][j] = (_Float16)0.f;
-                            Fl[k][dh][q][j] = (_Float16)0.f;
-                        }
-            }
-
-            // ---- one step; P = d & 1 (compile-time: it names the fragment sets and the accumulators) ----
-            // Vector-memory operations of a step, in this order (the counted waits rely on it): the mailbox operation (exactly
-            // one per step of a mailbox helper: a spare line takes the steps without one), the row whose first pixel is PF
-            // steps away (at the sweep's first step: all rows up to that one), and -- long after the last row load -- a row store.
-            // LDS operations of a wave complete in order: "all but the n youngest have" is one counted wait
-            constexpr int NFR = PER * (1 + (NEED1 ? 1 : 0) + (NEED2 ? 1 : 0)); // fragment reads of a step
-            static_assert(NFR <= 15, "the counted LDS waits fit the counter");
             floatx4 zh = {0.f, 0.f, 0.f, 0.f}, zm = {0.f, 0.f, 0.f, 0.f}; // z product of the previous step (diagonal d - ZLAG)
-            // A step is laid out around the chain wave's, which holds the matrix pipe from about a quarter to three quarters of
-            // the step: products whose operands are in registers FIRST (the chain wave is waiting for its fragments), everything
-            // that is not a product in the MIDDLE, the remaining products LAST (the chain wave is in its epilogue).
-            auto step = [&](auto p_c, const int d) {
-                constexpr int P = decltype(p_c)::value;
+
+            // ---- one step.  LD: the sweep's first steps, in which rows are requested and waited for; ST: its last ones, in
+            //      which rows leave (the step in between has neither: compile-time, so that it carries no test for them).
+            // The chain wave of this SIMD is the pole of the step and every instruction issued here takes an issue slot from
+            // it: a step is the z of the previous step into the tile, four fragment reads, six MFMAs, and little else.
+            // Vector-memory operations of a sweep, in this order (the counted waits rely on it): all rows; then per step the mailbox
+            // operation (exactly one per step of a mailbox helper: a spare line takes the steps without one) and -- long after
+            // the last row has landed -- a row store.
+            auto step = [&](auto ld_c, auto st_c, const int d) {
+                constexpr bool LD = decltype(ld_c)::value, ST = decltype(st_c)::value;
                 IFL_HSTAMP(6); // (the wait at the end of the previous step)
                 asm volatile("s_barrier" ::: "memory");
                 IFL_HSTAMP(0); // barrier
-                constexpr int srcoff = (P ^ 1) * SLOTB; // ring slot of diagonal d-1 (P = d & 1)
-                const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
-                // products on the fragments of r_{d-2} (in registers since the end of the last step)
-                auto mf = [&](int s, int dh, floatx4 &ah, floatx4 &am, bool init) {
+                const int srcoff = ((d + 1) & 1) * SLOTB; // ring slot of diagonal d-1
+                // ---- z of diagonal d - ZLAG (formed at the end of the previous step) -> the tile, over the x the chain consumed
+                //      ZLAG steps ago.  A column outside the image repeats an older pixel of its row (the ring keeps it) or is
+                //      zero: the maximum over everything formed is the maximum over the image.
+                if ((unsigned)(d - ZLAG) < (unsigned)ND && !(IFL_EXP & 2)) {
+                    const int t = d - ZLAG;
+                    const bool vz = hval && (unsigned)(t - n) < 32u;
+                    const unsigned za = tbase + ((crel + srel * t) & 127);
+                    float zv[4];
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        ah = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s][q][0], Fh[P ^ 1][dh][q], (init && q == 0) ? zero : ah, 0, 0, 0);
-                        am = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s][q][0], Fl[P ^ 1][dh][q], (init && q == 0) ? zero : am, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) am = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s][q][1], Fh[P ^ 1][dh][q], am, 0, 0, 0);
-                };
-                // ---- FIRST: the taps three diagonals back -> diagonal d+1 (joining what the tap four back left there a step ago)
-                if constexpr (Cfg::HAS_HT && !(IFL_EXP & 4)) {
-#pragma unroll
-                    for (int dh = 0; dh < KH; ++dh)
-#pragma unroll
-                        for (int dw = 0; dw < KW; ++dw)
-                            if (dh + dw == 3) mf(dh * KW + dw - 1, dh, hhi[P], hmid[P], false);
-                    asm volatile("" ::"a"(hhi[P]), "a"(hmid[P])); // (MFMAs are pure: tied to an opaque statement, or they sink)
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int r = 0; r < 4; ++r) zv[r] = (zh[r] + zm[r] * LO_INV) * zscale;
+                    tile_write4(vz ? za : hdump, zv[0], zv[1], zv[2], zv[3]);
+                    zmax = fmaxf(fmaxf(zmax, fmaxf(fabsf(zv[0]), fabsf(zv[1]))), fmaxf(fabsf(zv[2]), fabsf(zv[3])));
                 }
-                IFL_HSTAMP(1); // first products
-                // ---- MIDDLE.  z of diagonal d - ZLAG (formed at the end of the previous step) -> the tile, over the seeds the chain
-                //      consumed ZLAG steps ago
-                {
-                    const int wz = d - ZLAG - n;
-                    const bool vz = hval && (unsigned)wz < (unsigned)Ws;
-                    unsigned za = taddr(wz); // (computed for every lane, then selected: no branch)
-                    asm volatile("" : "+v"(za));
-                    if ((unsigned)(d - ZLAG) < (unsigned)ND && !(IFL_EXP & 2)) {
-                        float zv[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) zv[r] = (zh[r] + zm[r] * LO_INV) * zscale;
-                        tile_write4(vz ? za : hdump, zv[0], zv[1], zv[2], zv[3]);
-                        const float m = fmaxf(fmaxf(fabsf(zv[0]), fabsf(zv[1])), fmaxf(fabsf(zv[2]), fabsf(zv[3])));
-                        zmax = vz ? fmaxf(zmax, m) : zmax;
-                    }
-                }
-                // Row d+1 -- its first pixel is on diagonal d+1, whose seeds this step writes (2x2: which the chain reads next
-                // step) -- must have landed: all but the operations behind its DMAs, which are the rows after it (up to
-                // d - 1 + PF so far) and the mailbox operations of the steps since
-                if ((unsigned)(d + 1) < (unsigned)Hp) {
-                    const int nrow = Hp - d - 2 < PF - 2 ? Hp - d - 2 : PF - 2;
-                    const int nmb = d - 1 - dfirst < PF - 2 ? d - 1 - dfirst : PF - 2;
-                    wait_vm(CPH * (nrow < 0 ? 0 : nrow) + M * nmb);
-                }
-                // LDS requests, oldest first: the x of diagonal d+1 (to become its seeds) ...
-                const int w1 = d + 1 - n;
-                const bool v1 = hval && (unsigned)w1 < (unsigned)Ws;
-                const bool seed_due = Cfg::HAS_HT && (unsigned)(d + 1) < (unsigned)ND && !(IFL_EXP & 1); // (wave-uniform)
-                unsigned sa = taddr(w1);
-                asm volatile("" : "+v"(sa));
-                floatx2 xq[2];
-                if (seed_due) tile_read4(xq[0], xq[1], v1 ? sa : tidle);
-                // ... the mailbox line that landed (lower part): it was the FIRST vector-memory operation of step d - PFH; younger:
-                // the rows of the steps d - PFH .. d - 1 and the lines of the steps in between; rows 14, 15 of the diagonal the chain
-                // waves finished in the previous step (upper part) ...
+                // ---- LDS requests: the fragments of r_{d-1} for this step's z product (behind the chain waves' requests, which
+                //      went out right after the barrier) ...
+                half8 Fh[NQ], Fl[NQ];
+                if (!(IFL_EXP & 16)) lds_read_set<NQ, 0>(Fh, Fl, radr[0] + srcoff);
+                // ... the mailbox line that landed (lower part): it was the vector-memory operation of step d - PFH; younger: the
+                // lines of the steps in between; rows 14, 15 of the diagonal the chain waves finished in the previous step (upper
+                // part) ...
                 bool h_in = false, h_out = false;
                 floatx4_ hq;
                 uintx2 pv;
@@ -706,36 +793,31 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                     h_in = (unsigned)(d + 2) < n_hin && !dead;
                     h_out = (unsigned)(d - 15) < n_hout;
                     if (h_in) {
-                        const int r1 = d + PF < Hp ? d + PF : Hp, r0 = d + PF - PFH < Hp ? d + PF - PFH : Hp;
-                        wait_vm(CPH * (r1 - r0) + PFH - 1);
+                        wait_vm(PFH - 1);
                         lds_read_f32x4(hq, ldsbase + Cfg::OFF_HALO + (d & (Cfg::NHL - 1)) * 1024 + lane * 16);
                     }
                     if (h_out) asm volatile("ds_read_b64 %0, %1" : "=v"(pv) : "v"(madr + RBB + srcoff) : "memory");
                 }
-                // ... the row whose last z went into the tile a step ago (this wave's own channels: its own LDS writes,
-                // complete since the end of that step) on its way out ...
+                // ... the row whose last z went into the tile a step ago (this wave's own channels: its own LDS writes, complete
+                // since the end of that step) on its way out
                 const int rs = d - SLAG;
-                const bool st_due = (unsigned)rs < (unsigned)Hp && !(IFL_EXP & 64);
+                const bool st_due = ST && (unsigned)rs < (unsigned)Hp && !(IFL_EXP & 256);
                 floatx4 sv[CPH];
                 if (st_due) {
                     const unsigned la = tchunk + rs * Cfg::TROWB + lane * 16;
                     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(sv[0]), "=&v"(sv[1]) : "v"(la) : "memory");
                 }
-                // ... and the fragments of r_{d-1} for the NEXT step's products: nothing in this step waits for them, and here
-                // they queue behind the chain waves' requests of this step, which went out right after the barrier
-                if (!(IFL_EXP & 16)) {
-                    lds_read_set_a<NQ, srcoff>(Fh[P][0], Fl[P][0], radr[0]);
-                    if constexpr (NEED1) lds_read_set_a<NQ, srcoff>(Fh[P][1], Fl[P][1], radr[1]);
-                    if constexpr (NEED2) lds_read_set_a<NQ, srcoff>(Fh[P][2], Fl[P][2], radr[2]);
-                }
-                constexpr int NFRQ = (IFL_EXP & 16) ? 0 : NFR; // (younger than everything requested above)
                 __builtin_amdgcn_sched_barrier(0);
-                IFL_HSTAMP(2); // z, requests
-                // Vector-memory operations of a step, in this order (the counted waits rely on it): the mailbox operation (exactly
-                // one per step of a mailbox helper: a spare line takes the steps without one), the row whose first pixel is PF
-                // steps away (at the sweep's first step: all rows up to that one), and -- long after the last row load -- a row store.
+                IFL_HSTAMP(1); // z, requests
+                // ---- vector-memory requests (see the order above)
+                if constexpr (LD) {
+                    // Row d+1 -- its first pixel is on diagonal d+1, which the chain reads next step -- must have landed: all but
+                    // the operations behind its DMAs, which are the rows after it and the mailbox operations of the sweep's steps
+                    // so far (this step's comes behind this wait)
+                    if ((unsigned)(d + 1) < (unsigned)HR) wait_vm(CPH * (HR - d - 2) + M * (d - dfirst));
+                }
                 if (mb_in) {
-                    if constexpr (((-2 - PFH) & 1) == P) if (d == -2 - PFH) {
+                    if (d == -2 - PFH) {
                         // gate: the first line is requested once the upper part's diagonal 14 + GATE is visible, so that every
                         // later request (one per step, like the upper part's lines) finds its line; the steps before this one
                         // (this tile's first rows are on their way) did not have to wait for the upper part
@@ -759,8 +841,10 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                                  "global_load_lds_dwordx4 %1, %2 sc0 sc1" ::"s"(dst), "v"(lane * 16), "s"(line)
                                  : "memory", "m0");
                 }
-                // everything requested before the fragments has landed (they themselves may still be on their way)
-                lgkm_wait_n(NFRQ);
+                // everything requested from the LDS has landed
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) asm volatile("" : "+v"(Fh[q]), "+v"(Fl[q]));
                 if (mb_out) {
                     const int u = d - 1;
                     asm volatile("" : "+v"(pv));
@@ -770,28 +854,11 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                     char *line = mb + (size_t)(h_out ? u : DUO_LINES - 2) * DUO_LINEB;
                     asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(lane * 16), "v"(q), "s"(line) : "memory");
                 }
-                if (!(IFL_EXP & 64)) {
-                    if (d == dfirst)
-                        for (int r = 0; r < dfirst + PF && r < Hp; ++r) load_row(r);
-                    if (d + PF < Hp) load_row(d + PF);
-                }
-                // the row on its way out, second half
-                if (st_due) {
+                if (st_due) { // the row on its way out, second half
                     asm volatile("" : "+v"(sv[0]), "+v"(sv[1]));
                     char *dst = zg + row_off(rs);
                     store_piece(pgo, sv[0], dst);
                     store_piece(pgo + chunkB, sv[1], dst);
-                }
-                IFL_HSTAMP(3); // memory requests
-                // the seeds of diagonal d+1: x + this wave's partial sums, in place
-                if constexpr (Cfg::HAS_HT) {
-                    if (seed_due) {
-                        asm volatile("" : "+v"(xq[0]), "+v"(xq[1]));
-                        float sd[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) sd[r] = xq[r >> 1][r & 1] * xscale + (hhi[P][r] + hmid[P][r] * LO_INV);
-                        tile_write4(v1 ? sa : hdump, sd[0], sd[1], sd[2], sd[3]);
-                    }
                 }
                 // hand-off in: rows 14, 15 of the upper part's diagonal d + 16 join diagonal d of this tile's ring
                 if (h_in) {
@@ -800,44 +867,36 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                     if (!__all(q[1] == tag && q[3] == tag)) poll_line(d + 16, q);
                     if (mlane && !dead) {
                         const uintx2 v = {q[0], q[2]};
-                        asm volatile("ds_write_b64 %0, %1" ::"v"(madr + P * SLOTB), "v"(v) : "memory");
+                        asm volatile("ds_write_b64 %0, %1" ::"v"(madr + (d & 1) * SLOTB), "v"(v) : "memory");
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                IFL_HSTAMP(4); // hand-off in, seeds
-                // ---- LAST: z of diagonal d-2 (for the next step to put into the tile) and the tap four diagonals back, which opens
-                //      diagonal d+2
+                IFL_HSTAMP(2); // memory requests, hand-off in
+                // ---- z of diagonal d-1 = L^-1 r_{d-1}, for the next step to put into the tile (same products in the same order
+                //      as the whole-image kernel's z product)
                 if (!(IFL_EXP & 4)) {
-                    mf(NS - 1, 0, zh, zm, true);
-                    asm volatile("" ::"a"(zh), "a"(zm));
-                    if constexpr (Cfg::HAS_HT) {
-                        int nopen = 0;
+                    const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+                    zh = zero, zm = zero;
 #pragma unroll
-                        for (int dh = 0; dh < KH; ++dh)
-#pragma unroll
-                            for (int dw = 0; dw < KW; ++dw)
-                                if (dh + dw == 4) mf(dh * KW + dw - 1, dh, hhi[P ^ 1], hmid[P ^ 1], nopen++ == 0);
-                        asm volatile("" ::"a"(hhi[P ^ 1]), "a"(hmid[P ^ 1]));
+                    for (int q = 0; q < NQ; ++q) {
+                        zh = __builtin_amdgcn_mfma_f32_16x16x32_f16(Z[q][0], Fh[q], zh, 0, 0, 0);
+                        zm = __builtin_amdgcn_mfma_f32_16x16x32_f16(Z[q][0], Fl[q], zm, 0, 0, 0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) zm = __builtin_amdgcn_mfma_f32_16x16x32_f16(Z[q][1], Fh[q], zm, 0, 0, 0);
                 }
-                IFL_HSTAMP(5); // last products
-                // (everything this wave asked of the LDS is done before the barrier: the fragments for the next step have landed,
-                // the seeds and z are in the tile)
+                __builtin_amdgcn_sched_barrier(0);
+                IFL_HSTAMP(3); // z product
+                // (a hand-off write must be in the ring before the barrier)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int dh = 0; dh < KH; ++dh)
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) asm volatile("" : "+a"(Fh[P][dh][q]), "+a"(Fl[P][dh][q]));
             };
             {
-                int d = dfirst; // (even: -LEAD or -PF)
-                static_assert(PF % 2 == 0 && LEAD % 2 == 0, "the sweep starts at an even step");
-                for (; d + 1 <= DEND; d += 2) {
-                    step(std::integral_constant<int, 0>{}, d);
-                    step(std::integral_constant<int, 1>{}, d + 1);
-                }
-                if (d <= DEND) step(std::integral_constant<int, 0>{}, d);
+                using T = std::true_type;
+                using F = std::false_type;
+                int d = dfirst;
+                for (; d <= Hp - 2 && d <= DEND; ++d) step(T{}, F{}, d);
+                for (; d < SLAG && d <= DEND; ++d) step(F{}, F{}, d);
+                for (; d <= DEND; ++d) step(F{}, T{}, d);
             }
             // (the last rows' stores and the last mailbox operations are still on their way.  Another sweep reuses the
             // tile and waits for them; the last sweep of the launched pass lets the wave run on to the verdict)
@@ -852,7 +911,7 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                 zero_ring();
                 __syncthreads();
             }
-            helper_sweep(sweep_of(redo, redo ? k - nfirst : k), !redo && k + 1 == nfirst);
+            helper_sweep(sweep_of(redo, redo ? k - nfirst : k), !redo && k + 1 == nfirst, k == 0);
             if (redo || k + 1 < nfirst) __syncthreads();
             if (redo) {
                 if (k + 1 == nfirst + nredo) break;

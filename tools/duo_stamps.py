@@ -7,7 +7,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "inverse-flow_amd")); sys.path.insert(0, ROOT)
 import torch
-buf = torch.zeros(128, dtype=torch.int64, device="cuda")
+buf = torch.zeros(512, dtype=torch.int64, device="cuda")
 os.environ["IFL_STAMPS"] = str(buf.data_ptr())
 import invflow_hip as H
 H.LIB_PATH = os.path.join(ROOT, "inverse-flow_amd", "lib", "libinvflow_hip_stamps.so")
@@ -34,3 +34,13 @@ for part, name in ((0, "upper / single"), (1, "lower")):
     print("   helper 0: slow polls %d (spins %d), gate wait %.2f us" % (o[8], o[9], o[10] / 100.0))
     names = ["barrier", "products 1", "z, requests", "memory requests", "hand-off in, seeds", "products 2", "final wait"]
     print("   helper 0 cycles per step:", {n: o[16 + k] // max(steps, 1) for k, n in enumerate(names)})
+
+# per-step timeline of the chain wave 0 of image 0's workgroups: cycles between consecutive barriers, and of those the wait
+for part, name in ((0, "upper / single"), (1, "lower")):
+    o = s[128 + 128 * part:256 + 128 * part]
+    if not any(o):
+        continue
+    t = [o[2 * k] for k in range(64) if o[2 * k]]
+    w = [o[2 * k + 1] for k in range(64) if o[2 * k]]
+    print(name, "steps between barriers (cycles; in brackets: of which waiting at the barrier):")
+    print("  " + " ".join("%d[%d]" % (t[k + 1] - t[k], w[k + 1]) for k in range(len(t) - 1)))

@@ -7,7 +7,7 @@ cd $ROOT/inverse-flow_amd
 python build.py > /dev/null
 for a in "$@"; do
   e=${a%%:*}; f=${a#*:}
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=fast $f -c csrc/scan_duo.hip -o build/scan_duo_x$e.o 2>build/scan_duo_x$e.log || { grep -m3 error build/scan_duo_x$e.log; rm -f build/scan_duo_x$e.o; } &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=fast -fno-slp-vectorize $f -c csrc/scan_duo.hip -o build/scan_duo_x$e.o 2>build/scan_duo_x$e.log || { grep -m3 error build/scan_duo_x$e.log; rm -f build/scan_duo_x$e.o; } &
 done
 wait
 for a in "$@"; do

@@ -46,14 +46,19 @@ enum {
     IFL_FLAG_GENERAL_DIAG = 1u, /* divide by w[c,c,diag tap] instead of assuming 1 */
     IFL_FLAG_EXACT_F32 = 2u,    /* force the plain-fp32 arithmetic path (no split-precision MFMA) */
     IFL_FLAG_NO_MFMA = 4u,      /* force the general (any C, any K) VALU kernels */
-    IFL_FLAG_WHOLE_IMAGE = 8u   /* one workgroup per image even when a scan_state block is given (same bits either way) */
+    IFL_FLAG_WHOLE_IMAGE = 8u   /* one workgroup per image even when a scan_state block is given: with the block the same
+                                   two sweeps through the same mailbox, bit-identical; without one the round-1 whole-image
+                                   kernel (its own summation order: within the tolerance, not bit for bit) */
 };
 
 enum { IFL_OK = 0, IFL_EINVAL = -1, IFL_EUNSUPPORTED = -2, IFL_EWORKSPACE = -3, IFL_EHIP = -4 };
 
 enum { IFL_OP_INVERSE = 0, IFL_OP_FORWARD = 1, IFL_OP_BACKWARD = 2, IFL_OP_DY = 3, IFL_OP_DW = 4 };
 
-/* Library / ABI version (major*1000 + minor). */
+/* Library / ABI version (major*1000 + minor).
+ * 2.0 (2000): every entry point that scans takes the caller's `scan_state` block as an argument (there is no registry inside
+ *   the library); ifl_inverse_* rejects z aliasing x with IFL_EINVAL (the scans read x while z rows are already leaving);
+ *   *recon_loss RECEIVES the loss on every route (the library clears it; it does not accumulate into the caller's value). */
 int ifl_version(void);
 
 /* Message of the last failing call made by this thread ("" if none). */

@@ -269,7 +269,7 @@ using namespace ifl;
 
 extern "C" {
 
-int ifl_version(void) { return 1000; }
+int ifl_version(void) { return 2000; }
 
 void ifl_profile_enable(int on)
 {
@@ -455,7 +455,9 @@ int ifl_backward_f32(const float *gout, const float *z, const float *x, const fl
             IFL_FAIL(IFL_EWORKSPACE, "ifl_backward_f32: workspace too small: need %zu bytes, have %zu", cv.off, cv.cap);
         // d/dW of rw*mean_b||x - A z||^2 = -(2 rw / B) sum r (x) shifted z  -> fold into the dW reduction
         if (conv_eff_on_mfma(g, flags, pack)) {
-            // ... in the epilogue of the convolution A z itself: the residual never exists as a tensor
+            // ... in the epilogue of the convolution A z itself: the residual never exists as a tensor.  (The epilogue ADDS
+            // the squared residuals into *recon_loss: cleared here -- the caller's buffer "receives" the loss, invflow.h)
+            if (recon_loss) IFL_HIP(hipMemsetAsync(recon_loss, 0, sizeof(float), s));
             const ConvMix mp{u, x, 2.0f * recon_weight / (float)B, recon_loss, 1.0f / (float)B};
             if ((rc = run_conv_eff(z, w, weff, mix, nullptr, g, flags, pack, s, &mp))) return rc;
         } else {

@@ -172,6 +172,11 @@ int ifl_backward_bf16(const uint16_t *gout, const uint16_t *z, const uint16_t *x
                                 ws, ws_bytes, carry, scan_state, stream);
     if (B < 0 || C < 1 || H < 1 || W < 1) IFL_FAIL(IFL_EINVAL, "ifl_backward_bf16: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
     if (!gout || !w) IFL_FAIL(IFL_EINVAL, "ifl_backward_bf16: null tensor pointer");
+    // (nothing was asked for: as ifl_backward_f32, no launch)
+    if (!dx && !dw) {
+        if (recon_loss) IFL_HIP(hipMemsetAsync(recon_loss, 0, sizeof(float), (hipStream_t)stream));
+        return IFL_OK;
+    }
     if (ws_bytes < ifl_workspace_bytes_bf16(IFL_OP_BACKWARD, B, C, H, W, KH, KW, flags) || !ws)
         IFL_FAIL(IFL_EWORKSPACE, "ifl_backward_bf16: workspace of %zu bytes needed",
                  ifl_workspace_bytes_bf16(IFL_OP_BACKWARD, B, C, H, W, KH, KW, flags));

@@ -56,8 +56,14 @@ class PaddedConv2d(FlowLayer):
         return torch.flip(mask, dims) if dims else mask
 
     def reset_gradients(self):
-        if self.conv.weight.grad is not None:
-            self.conv.weight.grad = self.conv.weight.grad * self.mask.to(self.conv.weight.grad.device)
+        """in place (the reference assigns a new tensor, conv.py:99-100: that would take .grad out of a flat gradient bucket
+        and out of a captured graph's addresses); the mask is cached per device"""
+        g = self.conv.weight.grad
+        if g is not None:
+            m = getattr(self, "_grad_mask", None)
+            if m is None or m.device != g.device or m.dtype != g.dtype:
+                m = self._grad_mask = self.mask.to(device=g.device, dtype=g.dtype)
+            g.mul_(m)
 
     def forward(self, x, context=None, compute_expensive=None):
         return self.conv(F.pad(x, self.pad)), 0.0

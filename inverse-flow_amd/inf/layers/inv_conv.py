@@ -159,8 +159,15 @@ class _InvFlowBase(FlowLayer):
         return torch.flip(mask, dims) if dims else mask
 
     def reset_gradients(self):
-        if self.weight_fwd.grad is not None:
-            self.weight_fwd.grad = self.weight_fwd.grad * self.get_mask().to(self.weight_fwd.grad.device)
+        """Mask the gradient IN PLACE (inv_conv.py:223-230 assigns a new tensor: that would take .grad out of a flat gradient
+        bucket -- inf/train/step.py -- and out of a captured graph's addresses).  The mask is cached per device, so the
+        masking is one multiplication that captures into a graph."""
+        g = self.weight_fwd.grad
+        if g is not None:
+            m = getattr(self, "_grad_mask", None)
+            if m is None or m.device != g.device or m.dtype != g.dtype:
+                m = self._grad_mask = self.get_mask().to(device=g.device, dtype=g.dtype)
+            g.mul_(m)
 
     def add_recon_grad(self, recon_loss_weight_update=None):
         """||x - A A^-1 x||^2 is zero up to rounding for the exact inverse: the recon gradient of this

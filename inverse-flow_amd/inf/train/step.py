@@ -62,6 +62,39 @@ class TrainStep:
             for group in optimizer.param_groups:
                 if "capturable" in group:
                     group["capturable"] = True
+            self._make_capturable()
+
+    def _make_capturable(self):
+        """A captured optimizer step bakes every Python number it sees into its kernels.  The learning rate therefore
+        becomes a device tensor (torch's capturable Adam/AdamW read it on the device): `set_lr` and schedulers that assign
+        `group['lr']` through it change it in place and the next replay uses the new value (the reference's trainer changes
+        it per batch during warm-up, experiment.py:197+).  Optimizer state restored from a checkpoint lives on the CPU
+        (`step` counters): moved to the parameters' device here, which capturable optimizers require."""
+        dev = None
+        for group in self.optimizer.param_groups:
+            for p in group["params"]:
+                dev = p.device
+                break
+            if dev is not None:
+                break
+        if dev is None or dev.type != "cuda":
+            return
+        for group in self.optimizer.param_groups:
+            if "capturable" in group and not torch.is_tensor(group["lr"]):
+                group["lr"] = torch.tensor(float(group["lr"]), dtype=torch.float32, device=dev)
+        for st in self.optimizer.state.values():
+            for k, v in list(st.items()):
+                if torch.is_tensor(v) and v.device != dev:
+                    st[k] = v.to(dev)
+
+    def set_lr(self, lr):
+        """change the learning rate of every parameter group -- in place when it is a device tensor (graph=True), so that a
+        captured step picks it up"""
+        for group in self.optimizer.param_groups:
+            if torch.is_tensor(group["lr"]):
+                group["lr"].fill_(float(lr))
+            else:
+                group["lr"] = float(lr)
 
     def _agree_on_init(self, x):
         """ActNorm's data-dependent initialisation (actnorm.py:21-27) sees a different shard on every rank.

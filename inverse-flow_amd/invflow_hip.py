@@ -207,7 +207,7 @@ _scan_states = {}
 
 def scan_state(dev):
     """The block of the current stream of `dev`, or None while a stream without one is being captured (the scan then runs
-    one workgroup per image: same bits)."""
+    one workgroup per image on the round-1 kernel: the same result within the tolerance)."""
     stream = _raw_stream()  # (called under the device guard: the current device is `dev`)
     key = (torch.cuda.current_device(), stream)
     st = _scan_states.get(key)
@@ -367,7 +367,7 @@ def backward(g, z, w, order="TL", flags=0, x=None, recon_weight=0.0, need_dx=Tru
     if need_dw:
         dw = dw_out if dw_out is not None else torch.empty_like(w)
         _chk_tensor(dw, "dw")
-    rl = torch.zeros(1, dtype=torch.float32, device=dev) if recon else None
+    rl = torch.empty(1, dtype=torch.float32, device=dev) if recon else None  # (the library clears it: the call's loss, not a sum)
     L = lib()
     with _on(dev):
         nb = L.ifl_workspace_bytes(OP_BACKWARD, B, C, H, W, KH, KW, flags)

@@ -260,6 +260,19 @@ def test_recon_term_mfma_route(H, oracle, shape, order):
     assert rel_err(host(dx), u) < TOL
     assert rel_err(host(dw), dw_o) < TOL
     assert abs(float(rl) - (r ** 2).sum() / B) < 1e-4 * (r ** 2).sum() / B
+    # the caller's loss word RECEIVES the loss (invflow.h): through the C ABI with the word pre-filled with garbage, twice
+    L = H.lib()
+    gd, zd, xd, wd = dev(g), dev(z), dev(x), dev(w)
+    dx2, dw2 = torch.empty_like(gd), torch.empty_like(wd)
+    nb = L.ifl_workspace_bytes(H.OP_BACKWARD, B, C, Hh, Ww, K, K, 0)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    loss = torch.full((1,), 1.0e9, device="cuda")
+    for _ in range(2):
+        rc = L.ifl_backward_f32(gd.data_ptr(), zd.data_ptr(), xd.data_ptr(), wd.data_ptr(), dx2.data_ptr(), dw2.data_ptr(), rw,
+                                loss.data_ptr(), B, C, Hh, Ww, K, K, ORDERS.index(order), 0, ws.data_ptr(), nb, None,
+                                H.scan_state(gd.device).data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, H.last_error() if hasattr(H, "last_error") else rc
+        assert abs(float(loss) - (r ** 2).sum() / B) < 1e-4 * (r ** 2).sum() / B
     # and the reverse pass with its log-det, which shares the packing launch
     xh, ld = H.forward(dev(z), dev(w), order, 0, want_logdet=True)
     assert rel_err(host(xh), oracle.forward(z64, w64, 0, order, nthreads=8)) < TOL and float(ld.abs().max()) == 0.0

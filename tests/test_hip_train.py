@@ -202,3 +202,38 @@ def test_train_step_as_one_graph(fixture):
                 step(x[:3])
     np.testing.assert_allclose(seqs[1], seqs[0], rtol=2e-4)
     assert seqs[1][-1] < seqs[1][0]
+
+
+def test_clear_grads_keeps_the_bucket_and_changes_nothing(fixture):
+    """TrainStep(clear_grads=True) masks the inverse-flow layers' gradients in place (they are views of the flat bucket): a run
+    with it and a run without it take the same steps -- the library's dW is masked already -- eagerly and as a captured
+    graph, and every gradient still lives in the bucket afterwards (a replaced .grad would neither be zeroed nor
+    all-reduced, and a captured backward would keep accumulating into the warm-up tensor).  With graph=True the learning
+    rate is a device tensor: set_lr takes effect in the next replay."""
+    from inf.train.step import TrainStep
+    x = torch.from_numpy(fixture["x"]).float().cuda()
+    finals = {}
+    for graph in (False, True):
+        for clear in (False, True):
+            torch.manual_seed(0)
+            model = build(fixture)
+            step = TrainStep(model, torch.optim.Adam(model.parameters(), lr=1e-3), grad_clip_norm=1.0, clear_grads=clear, graph=graph,
+                             graph_warmup=2)
+            losses = [float(step(x)) for _ in range(6)]
+            lo, hi = step.bucket.flat.data_ptr(), step.bucket.flat.data_ptr() + step.bucket.flat.numel() * 4
+            assert all(lo <= p.grad.data_ptr() < hi for p in model.parameters())
+            finals[(graph, clear)] = (losses, torch.cat([p.detach().reshape(-1) for p in model.parameters()]))
+        la, pa = finals[(graph, False)]
+        lb, pb = finals[(graph, True)]
+        assert la == lb and torch.equal(pa, pb), graph
+    # the captured step reads the learning rate from the device
+    torch.manual_seed(0)
+    model = build(fixture)
+    step = TrainStep(model, torch.optim.Adam(model.parameters(), lr=1e-3), graph=True, graph_warmup=1)
+    for _ in range(3):
+        step(x)
+    assert step._captured is not None and torch.is_tensor(step.optimizer.param_groups[0]["lr"])
+    step.set_lr(0.0)
+    before = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+    step(x)
+    assert torch.equal(before, torch.cat([p.detach().reshape(-1) for p in model.parameters()]))

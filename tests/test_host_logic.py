@@ -140,3 +140,29 @@ def test_storage_format_of_an_activation_picks_the_entry_point():
         assert H.SIGNATURES[name + "_bf16"] == H.SIGNATURES[name + "_f32"]  # same argument lists: only the pointee differs
     with __import__("pytest").raises(RuntimeError):
         H.inverse(torch.zeros(1, 1, 2, 2, dtype=torch.bfloat16), torch.zeros(1, 1, 1, 1))  # CPU tensors: no fallback
+
+
+def test_gradient_masks_are_applied_in_place_and_stay_in_the_bucket():
+    """reset_gradients (inv_conv.py:223-230, conv.py:99-100) must not REPLACE .grad: the gradients are views of one flat bucket
+    that is zeroed and all-reduced as a whole (data_parallel.GradBucket), and a captured step keeps their addresses.  After
+    clear_grad every .grad still aliases the bucket, carries the mask, and bucket.zero() clears it."""
+    import data_parallel as dp
+    from inf.layers.conv import PaddedConv2d
+    from inf.train.step import clear_grad
+    torch.manual_seed(0)
+    mods = torch.nn.ModuleList([inv_flow_with_pad(6, 6, (3, 3), order="TR"), inv_flow_with_pad(6, 6, (2, 2), order="BL"),
+                                PaddedConv2d(6, 6, (3, 3), order="BR")])
+    bucket = dp.GradBucket(mods.parameters())
+    lo, hi = bucket.flat.data_ptr(), bucket.flat.data_ptr() + bucket.flat.numel() * 4
+    for rep in range(3):
+        bucket.flat.normal_()
+        before = [p.grad.clone() for p in mods.parameters()]
+        mods.apply(clear_grad)
+        mods[2].reset_gradients()
+        for p in mods.parameters():
+            assert lo <= p.grad.data_ptr() < hi
+        for m, g0 in ((mods[0], before[0]), (mods[1], before[1])):
+            assert torch.equal(m.weight_fwd.grad, g0 * m.get_mask()) and float((m.weight_fwd.grad == 0).sum()) > 0
+        assert torch.equal(mods[2].conv.weight.grad, before[2] * mods[2].mask)
+        bucket.zero()
+        assert all(float(p.grad.abs().sum()) == 0.0 for p in mods.parameters())

@@ -45,6 +45,10 @@ def parse_args():
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL)")
     ap.add_argument("--dry", action="store_true", help="no kernels, CPU tensors: exercises launch, sharding and the collective")
     ap.add_argument("--master-port", type=int, default=29533)
+    ap.add_argument("--workload", choices=("layer", "cifar_step", "imagenet32_step"), default="layer",
+                    help="layer: the headline metric (BASELINE configs[1]); cifar_step / imagenet32_step: the training step of "
+                         "configs[3] (batch 256) / configs[4] (batch 100), the batch sharded over the ranks")
+    ap.add_argument("--no-graph", action="store_true", help="model workloads: eager steps instead of one captured graph per step")
     return ap.parse_args()
 
 
@@ -189,15 +193,15 @@ def train_step_figure(dev, steps=20, warmup=5):
 def cifar_step_figure(dev, steps=10, warmup=5):
     """BASELINE configs[3]: if_glow_cifar (inf/experiments/if_glow_cifar.py:28-190: L = 2, K = 16, 3x3 inverse-flow layers,
     shared splines, coupling width 128) training step at one rank's shard of the batch of 256 over eight GPUs (32 images),
-    bf16 autocast, synthetic uniform-dequantised 32x32x3 images, as one captured graph.  ActNorm is ON (the configuration
-    runs without; see DESIGN 4.6: the reference's 3x3 initialisation is a shift for the exact operator).  Not part of `value`."""
+    bf16 autocast, synthetic uniform-dequantised 32x32x3 images, as one captured graph.  As configured: no ActNorm (the
+    layers start as the identity map, inf/layers/inv_conv.py _init_weight).  Not part of `value`."""
     import torch
     from inf.experiments.if_glow_cifar import DEFAULT_CONFIG as cfg, create_model
     from inf.train.step import TrainStep, bits_per_dim
     torch.manual_seed(4)
     model = create_model(inv_flow=cfg["inv_flow"], inv_conv=cfg["inv_conv"], inv_conv_no_pad=cfg["inv_conv_no_pad"],
                          if_kernel_size=cfg["if_kernel_size"], num_blocks=cfg["num_blocks"], block_size=cfg["block_size"],
-                         coupling_width=cfg["coupling_width"], activation=cfg["activation"], actnorm=True,
+                         coupling_width=cfg["coupling_width"], activation=cfg["activation"], actnorm=cfg["actnorm"],
                          split_prior=cfg["split_prior"]).to(dev)
     step = TrainStep(model, torch.optim.Adam(model.parameters(), lr=cfg["lr"]), grad_clip_norm=1.0, autocast=True, graph=True)
     nb = 32
@@ -211,7 +215,7 @@ def cifar_step_figure(dev, steps=10, warmup=5):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     return {"config": "configs[3]: if_glow_cifar L=2, K=16, 3x3 inverse-flow layers, coupling width 128, 32 images per rank (256 over "
-                      "8), 32x32x3, bf16 autocast, Adam, ActNorm on, synthetic data; one captured graph per step",
+                      "8), 32x32x3, bf16 autocast, Adam, as configured (no ActNorm), synthetic data; one captured graph per step",
             "ms_per_step": ms, "images_per_s": nb / (ms * 1e-3), "bits_per_dim": bits_per_dim(float(loss), 3 * 32 * 32),
             "parameters": sum(p.numel() for p in model.parameters()), "steps": steps}
 
@@ -264,6 +268,109 @@ def committed_counters(kernel_us, world):
         return None, None, None
 
 
+def model_workload(args, rank, local_rank, world):
+    """BASELINE configs[3] / configs[4]: the training step of the 32x32x3 Glow with inverse-flow layers (if_glow_cifar: batch
+    256; the multi-GPU ImageNet-32 model: batch 100), AS CONFIGURED, the batch sharded over the ranks (strong scaling: the
+    reference hands the whole batch to nn.DataParallel, inf/if_multiGPU_imagenet32.py:410-411), bf16 autocast, one captured
+    graph per step WITH the all-reduce of the flat gradient bucket inside it.  One JSON line: whole-job images/s, ms per step
+    (max over ranks), the all-reduce alone.  --dry: the same control flow on CPU tensors (model construction, bucket,
+    collective), no kernels."""
+    import importlib
+    import torch
+    import torch.distributed as dist
+    import data_parallel as dp
+    from inf.train.step import TrainStep, bits_per_dim
+    mod, total, tag = {"cifar_step": ("inf.experiments.if_glow_cifar", 256, "configs[3]: if_glow_cifar"),
+                       "imagenet32_step": ("inf.experiments.if_glow_imagenet32", 100, "configs[4]: if_multiGPU_imagenet32")}[args.workload]
+    m = importlib.import_module(mod)
+    cfg = m.DEFAULT_CONFIG
+    lo, hi = dp.shard_bounds(total, rank, world)
+    nb = hi - lo
+    torch.manual_seed(11)  # (the same model on every rank; broadcast below all the same)
+    model = m.create_model(inv_flow=cfg["inv_flow"], inv_conv=cfg["inv_conv"], inv_conv_no_pad=cfg["inv_conv_no_pad"],
+                           if_kernel_size=cfg["if_kernel_size"], num_blocks=cfg["num_blocks"], block_size=cfg["block_size"],
+                           coupling_width=cfg["coupling_width"], n_bins=cfg["n_bins"], tail_bound=cfg["tail_bound"],
+                           activation=cfg["activation"], actnorm=cfg["actnorm"], split_prior=cfg["split_prior"])
+    nparam = sum(p.numel() for p in model.parameters())
+    dev = torch.device("cpu") if args.dry else torch.device("cuda", local_rank)
+    model = model.to(dev)
+    dp.broadcast_parameters(model)
+    torch.manual_seed(100 + rank)
+    x = torch.randint(0, 256, (nb, 3, 32, 32), device=dev).float()
+    clip = cfg["grad_clip_norm"]
+    step = TrainStep(model, torch.optim.Adam(model.parameters(), lr=cfg["lr"]), grad_clip_norm=1.0 if clip is True else float(clip),
+                     autocast=True, graph=not (args.no_graph or args.dry))
+    loss = torch.zeros(())
+
+    def one():
+        if args.dry:  # no kernels: what a step does to the bucket between the backward and the optimizer
+            step.bucket.flat.fill_(float(rank + 1))
+            step.bucket.allreduce_mean()
+            return torch.zeros(())
+        return step(x)
+
+    for _ in range(args.warmup):
+        loss = one()
+    if not args.dry:
+        torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    if not args.dry:
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one()
+    if not args.dry:
+        torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    if not args.dry:
+        torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    # the collective alone (outside the timed region): the flat bucket, sum + scale
+    ar_us = None
+    if world > 1:
+        n_ar = 20
+        if args.dry:
+            t1 = time.perf_counter()
+            for _ in range(n_ar):
+                step.bucket.allreduce_mean()
+            ar_us = (time.perf_counter() - t1) / n_ar * 1e6
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            step.bucket.allreduce_mean()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(n_ar):
+                step.bucket.allreduce_mean()
+            e1.record()
+            torch.cuda.synchronize()
+            ar_us = e0.elapsed_time(e1) / n_ar * 1e3
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        print(json.dumps({
+            "metric": "%s training step images/sec (batch %d sharded over the ranks)" % (tag.split(": ")[1], total),
+            "value": total * args.steps / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16 autocast (library layers: f16x3-split MFMA on f32 storage, f32 accumulate)",
+            "data": "synthetic" if not args.dry else "none (dry run: no kernels)",
+            "config": {"workload": "%s L=%d, K=%d, coupling width %d, as configured (actnorm=%s), batch %d = %d per rank, 32x32x3, Adam, "
+                                   "%s" % (tag, cfg["num_blocks"], cfg["block_size"], cfg["coupling_width"], cfg["actnorm"], total, nb,
+                                           "one captured graph per step incl. the bucket all-reduce" if step.graph else "eager steps"),
+                       "per_rank_batch": nb, "parameters": nparam, "bucket_bytes": int(step.bucket.flat.numel()) * 4},
+            "allreduce_us": ar_us,
+            "bits_per_dim": None if args.dry else bits_per_dim(float(loss), 3 * 32 * 32),
+            "scaling_curve": "this line is ONE N; the 1/2/4/8 curve is measured by the driver from such lines (SCALE_rNN.json), "
+                             "or absent when no multi-GPU node was available",
+        }), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -276,6 +383,8 @@ def main():
     rank, local_rank, world = dp.init(args.backend or ("gloo" if args.dry else None))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the process group has %d ranks" % (args.gpus, world))
+    if args.workload != "layer":
+        return model_workload(args, rank, local_rank, world)
     nb = B if args.scaling == "weak" else dp.shard_bounds(B, rank, world)[1] - dp.shard_bounds(B, rank, world)[0]
     nb_total = B * world if args.scaling == "weak" else B
     gen = torch.Generator().manual_seed(0)

@@ -69,9 +69,10 @@ class GradBucket:
     def zero(self):
         self.flat.zero_()
 
-    def allreduce_mean(self, async_op=False):
-        """Sum over ranks, divide by the world size.  Returns the work handle when async_op."""
-        if not dist.is_initialized() or dist.get_world_size() == 1:
+    def allreduce_mean(self, async_op=False, force=False):
+        """Sum over ranks, divide by the world size.  Returns the work handle when async_op.  force: issue the collective in
+        a process group of one rank too (a no-op in value: what a test of the captured step needs)."""
+        if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
             return None
         world = dist.get_world_size()
         if async_op:

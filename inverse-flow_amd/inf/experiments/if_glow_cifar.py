@@ -28,7 +28,7 @@ DEFAULT_CONFIG = dict(num_blocks=2, block_size=16, coupling_width=128, batch_siz
 
 def create_model(inv_conv=False, inv_flow=True, inv_conv_no_pad=False, num_blocks=3, block_size=32, coupling_width=512,
                  if_kernel_size=3, tail_bound=30, n_bins=10, activation="Spline", actnorm=True, split_prior=True,
-                 image_size=(3, 32, 32), dequantize=True, split_width=512, spline_from_args=False):
+                 image_size=(3, 32, 32), dequantize=True, split_width=512, spline_from_args=False, reference_init=False):
     alpha = 1e-6
     bins, tail = (n_bins, tail_bound) if spline_from_args else (10, 20)
     acts = {"SLR": lambda size: SmoothLeakyRelu(alpha=0.3),
@@ -44,11 +44,11 @@ def create_model(inv_conv=False, inv_flow=True, inv_conv_no_pad=False, num_block
             if actnorm:
                 layers.append(ActNorm(size[0]))
             if inv_conv:
-                layers.append(inv_flow_with_pad(size[0], size[0], (3, 3), order="TL"))
+                layers.append(inv_flow_with_pad(size[0], size[0], (3, 3), order="TL", reference_init=reference_init))
             if inv_flow:
-                layers.append(inv_flow_with_pad(size[0], size[0], (if_kernel_size, if_kernel_size), order="TL"))
+                layers.append(inv_flow_with_pad(size[0], size[0], (if_kernel_size, if_kernel_size), order="TL", reference_init=reference_init))
             if inv_conv_no_pad:
-                layers.append(inv_flow_no_pad(size[0], size[0], (3, 3)))
+                layers.append(inv_flow_no_pad(size[0], size[0], (3, 3), reference_init=reference_init))
             if activation in acts and not (block == num_blocks - 1 and k == block_size - 1):
                 layers.append(acts[activation](size))
             layers.append(Coupling(size, width=coupling_width))

@@ -23,7 +23,7 @@ DEFAULT_CONFIG = dict(num_blocks=2, block_size=16, coupling_width=512, batch_siz
 
 def create_model(inv_flow=False, inv_conv_no_pad=True, if_kernel_size=3, coupling_width=512, num_blocks=2, block_size=16,
                  tail_bound=20, n_bins=5, actnorm=True, activation="Spline", split_prior=True, image_size=(1, 28, 28),
-                 dequantize=True, split_width=512):
+                 dequantize=True, split_width=512, reference_init=False):
     alpha = 1e-7
     acts = {"SLR": lambda size: SmoothLeakyRelu(alpha=0.3),
             "Spline": lambda size: SplineActivation(size, n_bins=n_bins, tail_bound=tail_bound, individual_weights=True)}
@@ -38,9 +38,9 @@ def create_model(inv_flow=False, inv_conv_no_pad=True, if_kernel_size=3, couplin
             if actnorm:
                 layers.append(ActNorm(size[0]))
             if inv_flow:
-                layers.append(inv_flow_with_pad(size[0], size[0], (if_kernel_size, if_kernel_size), order="TL"))
+                layers.append(inv_flow_with_pad(size[0], size[0], (if_kernel_size, if_kernel_size), order="TL", reference_init=reference_init))
             if inv_conv_no_pad:
-                layers.append(inv_flow_no_pad(size[0], size[0], (2, 2)))
+                layers.append(inv_flow_no_pad(size[0], size[0], (2, 2), reference_init=reference_init))
             if activation in acts:
                 layers.append(acts[activation](size))
             layers.append(Coupling(size, width=coupling_width))

@@ -88,13 +88,26 @@ def inv_conv_4d(x, W, order="TL", flags=0, recon_weight=0.0):
     return inv_conv_.apply(x, W, order, flags, recon_weight)
 
 
-def _init_weight(out_channels, in_channels, kernel_size):
-    """Identity + small noise, or a random orthogonal matrix for 1x1 (inv_conv.py:149-165)."""
+def _init_weight(out_channels, in_channels, kernel_size, reference_init=False):
+    """Identity + small noise, or a random orthogonal matrix for 1x1 (inv_conv.py:149-165).
+
+    Where the identity sits is the one deliberate difference from the reference's recipe.  nn.init.dirac_ puts it at the
+    kernel's CENTRE (inv_conv.py:154); the exact operator has its unit diagonal at the LAST tap (solve_mc.py:105-109), so
+    for a 3x3 kernel the reference's initial layer is the identity PLUS a one-pixel diagonal shift: its inverse amplifies
+    about 6x per layer and a Glow of 32 such layers without ActNorm (if_glow_cifar.py:147, if_multiGPU_imagenet32.py:284-345)
+    leaves fp32 on its first batch.  Default here: the identity at the operator's diagonal tap (the layer starts as the
+    identity map, like every other Glow layer); `reference_init=True` reproduces inv_conv.py:153-170 tap for tap.  For 2x2
+    kernels the two coincide.  Shapes and state-dict keys are the same either way."""
     w_shape = (out_channels, in_channels, *kernel_size)
     if kernel_size[0] == 1 and kernel_size[1] == 1:
         q = np.linalg.qr(np.random.randn(out_channels, in_channels))[0]
         return torch.tensor(q).to(torch.float).view(w_shape)
-    w = nn.init.dirac_(torch.empty(w_shape))
+    if reference_init:
+        w = nn.init.dirac_(torch.empty(w_shape))
+    else:
+        w = torch.zeros(w_shape)
+        for c in range(min(out_channels, in_channels)):
+            w[c, c, -1, -1] = 1.0
     return w + nn.init.xavier_normal_(torch.empty(w_shape), gain=0.01)
 
 
@@ -102,8 +115,9 @@ class _InvFlowBase(FlowLayer):
     order = "TL"
 
     def __init__(self, in_channels, out_channels, kernel_size, sym_recon_grad=False, only_R_recon=False,
-                 recon_loss_weight=1.0, recon_loss_lr=0.0, recon_alpha=0.9):
+                 recon_loss_weight=1.0, recon_loss_lr=0.0, recon_alpha=0.9, reference_init=False):
         super().__init__()
+        self.reference_init = reference_init  # (see _init_weight)
         assert len(kernel_size) == 2
         assert in_channels == out_channels, "an invertible convolution needs in_channels == out_channels"
         self.kernel_size = _pair(kernel_size)
@@ -120,7 +134,7 @@ class _InvFlowBase(FlowLayer):
 
     def reset_parameters(self):
         self.logabsdet_dirty = True
-        w = _init_weight(self.out_channels, self.in_channels, self.kernel_size)
+        w = _init_weight(self.out_channels, self.in_channels, self.kernel_size, self.reference_init)
         # the reference pins the last input channel of the diagonal tap (inv_conv.py:168-170); the
         # exact solver ignores it (unit diagonal, solve_mc.py:105-109) -- kept for state-dict parity
         w[:, -1, -1, -1] = 1.0

@@ -45,15 +45,16 @@ class _unit_fn(torch.autograd.Function):
 
 
 class Inv_FlowUnit(nn.Module):
-    def __init__(self, in_channels, out_channels, kernel_size):
+    def __init__(self, in_channels, out_channels, kernel_size, reference_init=False):
         super().__init__()
         if isinstance(kernel_size, int) or len(kernel_size) == 1:
             k = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
             kernel_size = (k, k)
-        self.conv_tl = inv_flow_with_pad(out_channels, out_channels, kernel_size, order="TL")
-        self.conv_tr = inv_flow_with_pad(out_channels, out_channels, kernel_size, order="TR")
-        self.conv_bl = inv_flow_with_pad(out_channels, out_channels, kernel_size, order="BL")
-        self.conv_br = inv_flow_with_pad(out_channels, out_channels, kernel_size, order="BR")
+        kw = dict(reference_init=reference_init)  # (inf/layers/inv_conv.py, _init_weight)
+        self.conv_tl = inv_flow_with_pad(out_channels, out_channels, kernel_size, order="TL", **kw)
+        self.conv_tr = inv_flow_with_pad(out_channels, out_channels, kernel_size, order="TR", **kw)
+        self.conv_bl = inv_flow_with_pad(out_channels, out_channels, kernel_size, order="BL", **kw)
+        self.conv_br = inv_flow_with_pad(out_channels, out_channels, kernel_size, order="BR", **kw)
 
     def _chain(self):
         return (self.conv_tl, self.conv_tr, self.conv_bl, self.conv_br)

@@ -47,10 +47,11 @@ class TrainStep:
     bucket; every launch of the library is stream-ordered and allocation-free, so it captures as it is."""
 
     def __init__(self, model, optimizer, add_recon_grad=False, grad_clip_norm=None, grad_clip=None, clear_grads=False,
-                 autocast=False, bucket=True, graph=False, graph_warmup=3):
+                 autocast=False, bucket=True, graph=False, graph_warmup=3, force_collective=False):
         self.model, self.optimizer = model, optimizer
         self.add_recon_grad, self.grad_clip_norm, self.grad_clip = add_recon_grad, grad_clip_norm, grad_clip
         self.clear_grads, self.autocast = clear_grads, autocast
+        self.force_collective = force_collective  # issue the bucket's all-reduce in a one-rank process group too (tests)
         # every parameter's .grad is a view of one flat buffer: zeroing and the all-reduce are one operation each
         self.bucket = dp.GradBucket(model.parameters()) if bucket else None
         self.graph, self.graph_warmup = graph, graph_warmup
@@ -151,7 +152,7 @@ class TrainStep:
         if self.clear_grads:  # experiment.py:255 (the reference does this on its 'test' branch only)
             self.model.apply(clear_grad)
         if self.bucket is not None:
-            self.bucket.allreduce_mean()
+            self.bucket.allreduce_mean(force=self.force_collective)
         if self.grad_clip_norm is not None:  # experiment.py:287-289
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip_norm)
         if self.grad_clip:  # experiment.py:292-296: the reference clamps the PARAMETERS of layers that have a gradient

@@ -137,3 +137,22 @@ def test_bench_launches_its_own_ranks(tmp_path):
                        env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        text=True, timeout=120)
     assert r.returncode != 0 and "process group has 1 ranks" in (r.stdout + r.stderr)
+
+
+def test_bench_model_workloads_shard_the_configured_batch(tmp_path):
+    """`bench.py --workload cifar_step|imagenet32_step --gpus 2 --backend gloo --dry`: BASELINE configs[3] / configs[4] -- the
+    models as configured, the batch of 256 / 100 sharded over the ranks, the flat gradient bucket all-reduced -- control flow
+    on CPU tensors (the models are built, nothing is launched)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(OMP_NUM_THREADS="1")
+    bench = os.path.join(ROOT, "bench.py")
+    for wl, total, per_rank, nparam_min in (("cifar_step", 256, 128, 600_000), ("imagenet32_step", 100, 50, 8_000_000)):
+        r = subprocess.run([sys.executable, bench, "--workload", wl, "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry", "--backend",
+                            "gloo", "--master-port", "29541"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                           timeout=600)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["per_rank_batch"] == per_rank
+        assert line["config"]["parameters"] > nparam_min and line["config"]["bucket_bytes"] == 4 * line["config"]["parameters"]
+        assert "actnorm=False" in line["config"]["workload"] and line["allreduce_us"] > 0 and "driver" in line["scaling_curve"]

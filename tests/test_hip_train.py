@@ -124,25 +124,34 @@ def test_cifar_shaped_glow_matches_reference_layers(cifar_fixture):
     assert all(np.isfinite(losses)) and losses[-1] < losses[0] and step._captured is not None
 
 
-def _one_step_at_config_size(module_name, cfg, per_rank_batch):
-    """(ActNorm is switched ON here although these two configurations run without it: the reference initialises a 3x3 layer
-    with the identity at the CENTRE tap (nn.init.dirac_, inv_conv.py:154), which for the exact operator -- unit diagonal at
-    the LAST tap -- is a shift by one pixel on top of the identity; its inverse amplifies about 6x per layer at
-    initialisation and 32 such layers in a row leave fp32.  With the 2x2 layers of the MNIST model the two taps coincide.)"""
+def _steps_at_config_size(module_name, cfg, per_rank_batch, actnorm=None):
+    """Three training steps of a model built exactly as its configuration says -- `actnorm` False for both 32x32x3
+    configurations (if_glow_cifar.py:147, if_multiGPU_imagenet32.py:284-345) -- on uniform noise.  The layers start as the
+    identity map (inf/layers/inv_conv.py _init_weight: the identity at the operator's diagonal tap; the reference's recipe
+    puts it at the kernel centre, which for the exact operator is a one-pixel shift whose inverse amplifies ~6x per layer and
+    takes a model of 32 such layers without ActNorm out of fp32 on its first batch: reference_init=True, exercised below
+    WITH ActNorm).  actnorm=None: as configured."""
     import importlib
     from inf.train.step import TrainStep, bits_per_dim
     create_model = importlib.import_module(module_name).create_model
     torch.manual_seed(1)
+    an = cfg["actnorm"] if actnorm is None else actnorm
     model = create_model(inv_flow=cfg["inv_flow"], inv_conv=cfg["inv_conv"], inv_conv_no_pad=cfg["inv_conv_no_pad"],
                          if_kernel_size=cfg["if_kernel_size"], num_blocks=cfg["num_blocks"], block_size=cfg["block_size"],
                          coupling_width=cfg["coupling_width"], n_bins=cfg["n_bins"], tail_bound=cfg["tail_bound"],
-                         activation=cfg["activation"], actnorm=True, split_prior=cfg["split_prior"]).cuda()
+                         activation=cfg["activation"], actnorm=an, split_prior=cfg["split_prior"],
+                         reference_init=(actnorm is True)).cuda()
     x = torch.randint(0, 256, (per_rank_batch, 3, 32, 32)).float().cuda()
     step = TrainStep(model, torch.optim.Adam(model.parameters(), lr=cfg["lr"]), grad_clip_norm=1.0, autocast=True)
-    l0 = float(step(x))
-    l1 = float(step(x))
-    assert np.isfinite(l0) and np.isfinite(l1)
-    assert 0.5 < bits_per_dim(l0, 3 * 32 * 32) < 100.0  # (uniform noise, an untrained model)
+    # (the variant with the reference's initialisation: two steps, as in round 2 -- 144 amplifying layers at the configured
+    # learning rate of 1e-3 on noise do not survive many more)
+    losses = [float(step(x)) for _ in range(3 if actnorm is None else 2)]
+    assert all(np.isfinite(losses)), losses
+    bpd = bits_per_dim(losses[0], 3 * 32 * 32)
+    if actnorm is None:
+        assert 2.0 < bpd < 12.0, bpd  # (uniform noise through an untrained model that starts as the identity: ~8 bits per dimension)
+    else:
+        assert 0.5 < bpd < 100.0, bpd
     # every inverse-flow layer of the model got a gradient through the library's fused backward
     from inf.layers.inv_conv import _InvFlowBase
     layers = [m for m in model.modules() if isinstance(m, _InvFlowBase)]
@@ -152,17 +161,22 @@ def _one_step_at_config_size(module_name, cfg, per_rank_batch):
 
 
 def test_config4_cifar_glow_at_its_own_size():
-    """if_glow_cifar as configured (if_glow_cifar.py:108-190: L = 2, K = 16, 3x3 inverse-flow layers, coupling width 128) at
-    BASELINE configs[3]'s per-GPU batch (256 over eight ranks): one training step on synthetic data."""
+    """if_glow_cifar AS CONFIGURED (if_glow_cifar.py:108-190: L = 2, K = 16, 3x3 inverse-flow layers, coupling width 128, no
+    ActNorm) at BASELINE configs[3]'s per-GPU batch (256 over eight ranks): three training steps on synthetic data; then the
+    variant with ActNorm and the reference's initialisation."""
     from inf.experiments.if_glow_cifar import DEFAULT_CONFIG
-    assert _one_step_at_config_size("inf.experiments.if_glow_cifar", DEFAULT_CONFIG, 32) == [12, 24]
+    assert DEFAULT_CONFIG["actnorm"] is False
+    assert _steps_at_config_size("inf.experiments.if_glow_cifar", DEFAULT_CONFIG, 32) == [12, 24]
+    assert _steps_at_config_size("inf.experiments.if_glow_cifar", DEFAULT_CONFIG, 32, actnorm=True) == [12, 24]
 
 
 def test_config5_imagenet32_glow_at_its_own_size():
-    """The multi-GPU ImageNet-32 model as configured (if_multiGPU_imagenet32.py:284-345: L = 3, K = 48, coupling width 256):
-    one training step at a rank's shard of the batch of 100 over eight ranks."""
+    """The multi-GPU ImageNet-32 model AS CONFIGURED (if_multiGPU_imagenet32.py:284-345: L = 3, K = 48, coupling width 256, no
+    ActNorm): three training steps at a rank's shard of the batch of 100 over eight ranks; then the ActNorm variant."""
     from inf.experiments.if_glow_imagenet32 import DEFAULT_CONFIG
-    assert _one_step_at_config_size("inf.experiments.if_glow_imagenet32", DEFAULT_CONFIG, 13) == [12, 24, 48]
+    assert DEFAULT_CONFIG["actnorm"] is False
+    assert _steps_at_config_size("inf.experiments.if_glow_imagenet32", DEFAULT_CONFIG, 13) == [12, 24, 48]
+    assert _steps_at_config_size("inf.experiments.if_glow_imagenet32", DEFAULT_CONFIG, 13, actnorm=True) == [12, 24, 48]
 
 
 def test_config3_model_builds_at_its_own_size():
@@ -237,3 +251,44 @@ def test_clear_grads_keeps_the_bucket_and_changes_nothing(fixture):
     before = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
     step(x)
     assert torch.equal(before, torch.cat([p.detach().reshape(-1) for p in model.parameters()]))
+
+
+COLLECTIVE_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))   # RCCL, one rank: the collective is real, its value a no-op
+from test_hip_train import build
+from inf.train.step import TrainStep
+d = np.load(%r); fixture = {k: d[k] for k in d.files}
+x = torch.from_numpy(fixture["x"]).float().cuda()
+seqs = []
+for graph, force in ((False, False), (True, True)):
+    torch.manual_seed(0)
+    model = build(fixture)
+    step = TrainStep(model, torch.optim.Adam(model.parameters(), lr=1e-3), grad_clip_norm=1.0, graph=graph, graph_warmup=2,
+                     force_collective=force)
+    seqs.append([float(step(x)) for _ in range(8)])
+    if graph:
+        assert step._captured is not None
+assert seqs[0] == seqs[1], seqs
+dist.destroy_process_group()
+print("captured step with the collective: ok")
+'''
+
+
+def test_captured_step_with_the_bucket_all_reduce_inside(tmp_path):
+    """TrainStep(graph=True) in a process group: the all-reduce of the flat gradient bucket is captured WITH the step (RCCL,
+    backend "nccl", here a group of one rank -- the collective kernel is issued, its result is the identity) and the replays
+    give the loss sequence of the eager step without it.  Its own process: the process group must not leak into the suite."""
+    import subprocess
+    import sys
+    from conftest import PKG, ROOT
+    script = tmp_path / "w.py"
+    script.write_text(COLLECTIVE_WORKER % (PKG, ROOT, os.path.join(ROOT, "tests"), os.path.join(GOLDEN, "trainstep_glow_b6_8x8_L2K2.npz")))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "captured step with the collective: ok" in r.stdout, r.stdout[-3000:]

@@ -29,7 +29,7 @@ def test_abcs():
 def test_init_and_mask(order, oracle):
     torch.manual_seed(0)
     C, K = 6, 3
-    layer = inv_flow_with_pad(C, C, (K, K), order=order)
+    layer = inv_flow_with_pad(C, C, (K, K), order=order, reference_init=True)
     w = layer.weight_fwd.detach()
     assert w.shape == (C, C, K, K) and layer.weight_fwd.requires_grad
     assert list(layer.state_dict().keys()) == ["weight_fwd"]  # checkpoint key of the reference (inv_conv.py:165)
@@ -38,6 +38,13 @@ def test_init_and_mask(order, oracle):
     wt = torch.flip(w, dims) if dims else w
     assert torch.all(wt[:, -1, -1, -1] == 1.0)
     assert torch.allclose(wt[torch.arange(C - 1), torch.arange(C - 1), K // 2, K // 2], torch.ones(C - 1), atol=0.05)
+    # the default: the identity at the operator's diagonal tap (the layer starts as the identity map; README deviation 9) --
+    # same shape, same key, nothing but noise at the centre
+    safe = inv_flow_with_pad(C, C, (K, K), order=order)
+    ws = torch.flip(safe.weight_fwd.detach(), dims) if dims else safe.weight_fwd.detach()
+    assert ws.shape == w.shape and list(safe.state_dict().keys()) == ["weight_fwd"]
+    assert torch.allclose(ws[torch.arange(C), torch.arange(C), -1, -1], torch.ones(C), atol=0.05)
+    assert float(ws[:, :, K // 2, K // 2].abs().max()) < 0.05
     # mask = reference get_mask (inv_conv.py:233-248) = oracle mask
     m = layer.get_mask().numpy()
     assert np.array_equal(m, oracle.mask(C, K, K, 0, order))

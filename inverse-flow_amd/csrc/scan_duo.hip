@@ -107,6 +107,9 @@ template <int C, int KH, int KW> struct DuoCfg {
 #ifndef IFL_WEAVE
 #define IFL_WEAVE 4 // instructions of the chain's epilogue per trailing MFMA
 #endif
+#ifndef IFL_HELPER_SLEEP
+#define IFL_HELPER_SLEEP 0 // x 64 cycles: what a helper waits behind the barrier before it touches the LDS (the chain waves' requests first)
+#endif
 #ifndef IFL_PRIO_CHAIN
 #define IFL_PRIO_CHAIN 2
 #endif
@@ -283,6 +286,7 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
 
 #ifdef IFL_STAMPS
     unsigned long long st_rt[4] = {__builtin_amdgcn_s_memrealtime(), 0, 0, 0}, st_mt[2] = {0, 0}, st_bar = 0;
+    unsigned long long st_c[5] = {0, 0, 0, 0, 0}, st_cl = __builtin_amdgcn_s_memtime();
 #endif
 
     // The sweeps a workgroup runs, in order.  Launched tile(s) first: a split launch's workgroup has one (its part), a
@@ -372,6 +376,18 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                     F2l[q][j] = (_Float16)0.f;
                 }
 
+#ifdef IFL_STAMPS
+#define IFL_CSTAMP(k)                                                 \
+    do {                                                              \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
+        st_c[k] += t_ - st_cl;                                        \
+        st_cl = t_;                                                   \
+    } while (0)
+#else
+#define IFL_CSTAMP(k) \
+    do {              \
+    } while (0)
+#endif
             auto step = [&](auto r_c, const int d) {
                 constexpr int R = decltype(r_c)::value; // (d + 1) mod 3
                 constexpr int A0 = R, A1 = (R + 1) % 3, A2 = (R + 2) % 3; // accumulators of the diagonals d, d+1, d+2
@@ -384,12 +400,16 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
 #ifdef IFL_STAMPS
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
+                st_c[4] += tb0 - st_cl; // (section 4: the trailing products and the epilogue, up to the drained ring write)
+                st_cl = tb0;
 #endif
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #ifdef IFL_STAMPS
                 {
                     const unsigned long long tb1 = __builtin_amdgcn_s_memtime();
                     st_bar += tb1 - tb0;
+                    st_c[0] += tb1 - st_cl; // (section 0: at the barrier)
+                    st_cl = tb1;
                     // per-step timeline of image 0: when this wave passed barrier d, and how long it had waited there
                     if (g_stamps && b == 0 && tid == 0 && d - sw.dfirst < 64) {
                         g_stamps[128 + (my_part == 1 ? 128 : 0) + 2 * (d - sw.dfirst)] = tb1;
@@ -406,10 +426,9 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                 const unsigned xa = valid ? tbase + ((crel + srel * d) & 127) : tidle;
                 floatx2 xq[2];
                 half8 Fh[2][NQ], Fl[2][NQ];
+                // (the fragments first, in the order of their use; x -- wanted by the epilogue only -- last)
                 auto request = [&](int j) {
                     int c = 0;
-                    if (c++ == j) asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:32" : "=v"(xq[0]) : "v"(xa));
-                    if (c++ == j) asm volatile("ds_read2_b32 %0, %1 offset0:64 offset1:96" : "=v"(xq[1]) : "v"(xa));
 #pragma unroll
                     for (int dh = 0; dh < NDH; ++dh) {
                         const unsigned fa = radr[dh] + srcoff;
@@ -420,6 +439,8 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                             if (c++ == j) lds_read_b128_o<12 * 256>(Fl[dh][1], fa);
                         }
                     }
+                    if (c++ == j) asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:32" : "=v"(xq[0]) : "v"(xa));
+                    if (c++ == j) asm volatile("ds_read2_b32 %0, %1 offset0:64 offset1:96" : "=v"(xq[1]) : "v"(xa));
                 };
                 __builtin_amdgcn_sched_barrier(0);
                 // The destination of an asynchronous LDS read must stay allocated until the wait that covers it: as an operand of
@@ -474,6 +495,7 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                     for (int j = 0; j < NREQ; ++j) request(j);
                     fence();
                 }
+                IFL_CSTAMP(1); // leading products + requests (the stamp waits for the requests: they are due at the next wait anyway)
                 // ---- critical: taps (0,1) and (1,0) of r_{d-1} -> diagonal d.  The dh=2 fragments of r_{d-1} (next
                 //      step's leading operands; every MFMA that reads the old ones has been issued) ride behind the first
                 auto request2 = [&](int j) {
@@ -487,8 +509,7 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                     }
                 };
                 if constexpr (KW > 1) {
-                    lgkm_wait_n((NDH - 1) * PER); // x and the dh=0 fragments have landed
-                    asm volatile("" : "+v"(xq[0]), "+v"(xq[1]));
+                    lgkm_wait_n((NDH - 1) * PER + 2); // the dh=0 fragments have landed
                     landed(0);
 #pragma unroll
                     for (int k = 0; k < GM; ++k) {
@@ -503,11 +524,15 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                     fence();
                 }
                 if constexpr (KH > 1) {
-                    lgkm_wait_n(NRD2); // ... and the dh=1 fragments
+                    lgkm_wait_n(NRD2 + 2); // ... and the dh=1 fragments (behind them: x, and the dh=2 fragments of the next step)
                     landed(1);
                     mf(KW, Fh[1], Fl[1], A0);
                     fence();
                 }
+                // x has landed (for the epilogue; the next step's dh=2 fragments may still be on their way)
+                lgkm_wait_n(NRD2);
+                asm volatile("" : "+v"(xq[0]), "+v"(xq[1]));
+                IFL_CSTAMP(2); // critical products
                 // ---- trailing: the remaining taps of r_{d-1} (targets d+1, d+2) with the chain's epilogue woven in
                 const floatx4 head_hi = ahi[A0], head_mid = amid[A0];
 #pragma unroll
@@ -602,6 +627,7 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                 o[0] = st_rt[0], o[1] = st_rt[1], o[2] = st_rt[2], o[3] = st_mt[1] - st_mt[0];
                 o[4] = (unsigned long long)(s0.Hp + W - 1 + SLAG - 32 - s0.dfirst + 1);
                 o[5] = st_bar;
+                for (int j = 0; j < 5; ++j) o[24 + j] = st_c[j];
             }
 #endif
             int bad = __syncthreads_or(rmax < 6.0e4f ? 0 : 1);
@@ -766,10 +792,17 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                 asm volatile("s_barrier" ::: "memory");
                 IFL_HSTAMP(0); // barrier
                 const int srcoff = ((d + 1) & 1) * SLOTB; // ring slot of diagonal d-1
+                if (IFL_HELPER_SLEEP) __builtin_amdgcn_s_sleep(IFL_HELPER_SLEEP);
+                // ---- LDS requests: the fragments of r_{d-1} for this step's z product FIRST -- the wave's longest dependent
+                //      path is barrier -> fragments -> six MFMAs -> barrier, and the z of the previous step below (some twenty
+                //      vector instructions) runs while they are on their way ...
+                half8 Fh[NQ], Fl[NQ];
+                if (!(IFL_EXP & 16)) lds_read_set<NQ, 0>(Fh, Fl, radr[0] + srcoff);
                 // ---- z of diagonal d - ZLAG (formed at the end of the previous step) -> the tile, over the x the chain consumed
                 //      ZLAG steps ago.  A column outside the image repeats an older pixel of its row (the ring keeps it) or is
                 //      zero: the maximum over everything formed is the maximum over the image.
-                if ((unsigned)(d - ZLAG) < (unsigned)ND && !(IFL_EXP & 2)) {
+                const bool z_due = (unsigned)(d - ZLAG) < (unsigned)ND && !(IFL_EXP & 2);
+                if (z_due) {
                     const int t = d - ZLAG;
                     const bool vz = hval && (unsigned)(t - n) < 32u;
                     const unsigned za = tbase + ((crel + srel * t) & 127);
@@ -779,10 +812,6 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                     tile_write4(vz ? za : hdump, zv[0], zv[1], zv[2], zv[3]);
                     zmax = fmaxf(fmaxf(zmax, fmaxf(fabsf(zv[0]), fabsf(zv[1]))), fmaxf(fabsf(zv[2]), fabsf(zv[3])));
                 }
-                // ---- LDS requests: the fragments of r_{d-1} for this step's z product (behind the chain waves' requests, which
-                //      went out right after the barrier) ...
-                half8 Fh[NQ], Fl[NQ];
-                if (!(IFL_EXP & 16)) lds_read_set<NQ, 0>(Fh, Fl, radr[0] + srcoff);
                 // ... the mailbox line that landed (lower part): it was the vector-memory operation of step d - PFH; younger: the
                 // lines of the steps in between; rows 14, 15 of the diagonal the chain waves finished in the previous step (upper
                 // part) ...
@@ -841,8 +870,10 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                                  "global_load_lds_dwordx4 %1, %2 sc0 sc1" ::"s"(dst), "v"(lane * 16), "s"(line)
                                  : "memory", "m0");
                 }
-                // everything requested from the LDS has landed
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // the fragments have landed (LDS operations complete in order: behind them only the two writes of z may still be on
+                // their way, unless a mailbox or store read -- wanted right below -- is younger still)
+                if (mbox || st_due) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                else lgkm_wait_n(z_due ? 2 : 0);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) asm volatile("" : "+v"(Fh[q]), "+v"(Fl[q]));
                 if (mb_out) {

@@ -31,6 +31,8 @@ for part, name in ((0, "upper / single"), (1, "lower")):
           % (name, (o[0] - t0) / 100.0, (o[1] - t0) / 100.0, (o[2] - t0) / 100.0, steps, o[3] // max(steps, 1),
              o[3] / max((o[2] - o[1]) * 10.0, 1.0)))
     print("   chain wave 0: %d cycles per step at the barrier" % (o[5] // max(steps, 1)))
+    print("   chain wave 0 cycles per step:", {n_: o[24 + k] // max(steps, 1) for k, n_ in enumerate(
+        ["barrier", "leading products + requests", "critical products", "-", "trailing products + epilogue + drained ring write"]) if n_ != "-"})
     print("   helper 0: slow polls %d (spins %d), gate wait %.2f us" % (o[8], o[9], o[10] / 100.0))
     names = ["barrier", "products 1", "z, requests", "memory requests", "hand-off in, seeds", "products 2", "final wait"]
     print("   helper 0 cycles per step:", {n: o[16 + k] // max(steps, 1) for k, n in enumerate(names)})

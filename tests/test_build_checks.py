@@ -125,6 +125,86 @@ def test_the_walk_finds_a_planted_hazard():
     assert async_read_violations(bad) and not async_read_violations(good)
 
 
+def asm_memory_hazards(lines):
+    """Hazards nobody inserts wait states for around an inline-asm vector-memory instruction on gfx950 (each cost a
+    GPU fault or a wrong store in round 2).  Walks the listing and reports, for instructions INSIDE asm statements only (the
+    compiler pads its own):
+      A  a scalar register written by a vector instruction (v_readlane / v_readfirstlane: a spill reload) or m0 written by
+         s_mov, used by a global_/buffer_ instruction less than 5 wait states later;
+      B  a store of more than 8 bytes whose data registers are written less than 2 wait states later."""
+    viol = []
+    in_asm = False
+    recent = []  # (states ago, scalar registers written by VALU / m0)
+    last_store = None  # (data regs, states since)
+    def sregs(tok):
+        m = re.fullmatch(r"s(\d+)", tok)
+        if m:
+            return {int(m.group(1))}
+        m = re.fullmatch(r"s\[(\d+):(\d+)\]", tok)
+        return set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set()
+    for ln in lines:
+        t = ln.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
+            continue
+        code = t.split(";")[0].strip()
+        if not code:
+            continue
+        op = code.split()[0]
+        states = int(code.split()[1]) + 1 if op == "s_nop" else 1
+        stoks = re.findall(r"s\[\d+:\d+\]|\bs\d+\b", code)
+        vtoks = re.findall(r"[va]\[\d+:\d+\]|\b[va]\d+\b", code)
+        if in_asm and (op.startswith("global_") or op.startswith("buffer_")):
+            used = set().union(*[sregs(x) for x in stoks]) if stoks else set()
+            for age, regs in recent:
+                if age < 5 and ((used & regs) or ("m0" in regs and "lds" in op)):
+                    viol.append(("A", code, age))
+        if last_store is not None:
+            regs, age = last_store
+            written = _regs(vtoks[0]) if (vtoks and not op.startswith("global_store") and not op.startswith("ds_write")
+                                          and not op.startswith("s_")) else set()
+            if age < 2 and (written & regs):
+                viol.append(("B", code, age))
+            last_store = (regs, age + states) if age + states < 2 else None
+        if in_asm and re.match(r"global_store_dwordx[34]", op):
+            last_store = (_regs(vtoks[1]) if len(vtoks) > 1 else set(), 0)
+        recent = [(age + states, regs) for age, regs in recent if age + states < 5]
+        if op in ("v_readlane_b32", "v_readfirstlane_b32") and stoks:
+            recent.append((0, sregs(stoks[0])))
+        if op == "s_mov_b32" and code.split()[1].rstrip(",") == "m0":
+            recent.append((0, {"m0"}))
+    return viol
+
+
+def test_asm_memory_instructions_keep_their_wait_states(isa, tmp_path):
+    """scan_duo.hip and wide.hip: the vector-memory instructions issued from inline asm (LDS-DMA of the rows and of the mailbox
+    lines, whole-line stores, the fold's hand-issued loads) keep the wait states of hazards A and B; the walk itself is
+    checked on planted cases."""
+    assert asm_memory_hazards([";;#ASMSTART", "s_mov_b32 m0, s3", "global_load_lds_dwordx4 v1, s[4:5]", ";;#ASMEND"])
+    assert not asm_memory_hazards([";;#ASMSTART", "s_mov_b32 m0, s3", "s_nop 4", "global_load_lds_dwordx4 v1, s[4:5]", ";;#ASMEND"])
+    assert asm_memory_hazards(["v_readlane_b32 s4, v9, 3", ";;#ASMSTART", "s_nop 1", "global_store_dwordx4 v1, v[4:7], s[4:5]", ";;#ASMEND"])
+    assert asm_memory_hazards([";;#ASMSTART", "s_nop 4", "global_store_dwordx4 v1, v[4:7], s[4:5]", ";;#ASMEND", "v_mov_b32_e32 v5, 0"])
+    assert not asm_memory_hazards([";;#ASMSTART", "s_nop 4", "global_store_dwordx4 v1, v[4:7], s[4:5]", "s_nop 1", ";;#ASMEND",
+                                   "v_mov_b32_e32 v5, 0"])
+    bodies, _ = kernels(isa)
+    out = str(tmp_path / "wide.s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-Wno-inline-asm", "-S",
+                    "--cuda-device-only", "-o", out, os.path.join(PKG, "csrc", "wide.hip")], check=True, stdout=subprocess.PIPE,
+                   stderr=subprocess.PIPE)
+    wbodies, _ = kernels(open(out).read())
+    n_asm_mem = 0
+    for name, lines in list(bodies.items()) + list(wbodies.items()):
+        n_asm_mem += sum(1 for ln in lines if re.match(r"\s*(global_load_lds|global_store_dwordx4|global_load_dwordx4)", ln))
+        viol = asm_memory_hazards(lines)
+        assert not viol, (name, viol[:6])
+    assert n_asm_mem > 20
+
+
 def test_wide_kernels_fit_their_launches(tmp_path):
     """wide.hip: the team scan must keep its register image of the folded taps without spilling (a resident team member that
     spills would pay a scratch round trip per diagonal), and a team member of 8 waves must fit two waves per SIMD; the fold

@@ -172,9 +172,14 @@ static bool carry_usable(const Geom &g, unsigned flags)
 //   carry_out (forward): also fold the adjoint into the carry and collect max|z| there.
 //   carry_in (backward, transposed): take the packed adjoint from the carry, collect max|dx| there.
 // *amax_valid tells the caller whether the scan wrote max|output| into the carry word.
-static int run_scan(const float *x, const float *w, float *z, const Geom &g, int transposed, unsigned flags,
+static int run_scan(const ScanIO &io, const float *w, const Geom &g, int transposed, unsigned flags,
                     Carver &cv, void *carry_out, void *carry_in, bool *amax_valid, void *scan_state, hipStream_t s)
 {
+    // (bf16 storage -- x16 / z16 -- is taken by the duo scan only: native_bf16_ok() is what the *_bf16 entry points ask first)
+    const float *x = io.x32;
+    float *z = io.z32;
+    const void *xa = io.x16 ? (const void *)io.x16 : (const void *)io.x32;
+    const void *za = io.z32 ? (const void *)io.z32 : (const void *)io.z16;
     const size_t cp = cpad(g.C);
     double *linv = cv.take<double>(cp * cp);
     float *wf = cv.take<float>((size_t)g.KH * g.KW * cp * cp); // folded taps (fp32) or packed fp16 hi/lo fragments
@@ -186,7 +191,9 @@ static int run_scan(const float *x, const float *w, float *z, const Geom &g, int
     const int rh = g.flipH ^ (transposed ? 1 : 0), rw = g.flipW ^ (transposed ? 1 : 0);
     const bool usable = carry_usable(g, flags);
     const bool team_shape = usable && scan_team_supported(g);
-    const bool mfma = usable && !team_shape && scan_mfma_supported(g, x, z);
+    const bool mfma = usable && !team_shape && scan_mfma_supported(g, xa, za) && !(((uintptr_t)io.z16) & 15);
+    if ((io.x16 || io.z16) && !(mfma && scan_duo_route(g, scan_state, (flags & IFL_FLAG_WHOLE_IMAGE) != 0)))
+        IFL_FAIL(IFL_EUNSUPPORTED, "bf16 storage: this shape does not take the duo scan");
     CarryView co{}, ci{};
     if (carry_out && usable) co = carry_view(carry_out, g.C, g.KH, g.KW);
     if (carry_in && usable) ci = carry_view(carry_in, g.C, g.KH, g.KW);
@@ -241,7 +248,7 @@ static int run_scan(const float *x, const float *w, float *z, const Geom &g, int
         if (amax_valid) *amax_valid = amax != nullptr;
         // (an image whose r leaves the fp16 range is redone in exact fp32 inside the same launch)
         ProfScope ps(IFL_PROF_SCAN, s);
-        return launch_scan_mfma(x, pack, z, g, rh, rw, ovf, pack32, amax, scan_state, (flags & IFL_FLAG_WHOLE_IMAGE) != 0, s);
+        return launch_scan_mfma(io, pack, g, rh, rw, ovf, pack32, amax, scan_state, (flags & IFL_FLAG_WHOLE_IMAGE) != 0, s);
     }
     {
         ProfScope ps(IFL_PROF_FOLD, s);
@@ -266,6 +273,35 @@ static void order_pads(const Geom &g, int &pt, int &pl, int &dkh, int &dkw)
 } // namespace ifl
 
 using namespace ifl;
+
+namespace ifl {
+
+bool native_bf16_ok(int B, int C, int H, int W, int KH, int KW, int order, unsigned flags, const void *scan_state, const void *a,
+                    const void *b)
+{
+    if (B < 1 || (((uintptr_t)a | (uintptr_t)b) & 15)) return false;
+    const Geom g = make_geom(B, C, H, W, KH, KW, order, flags);
+    return carry_usable(g, flags) && !scan_team_supported(g) && scan_duo_route(g, scan_state, (flags & IFL_FLAG_WHOLE_IMAGE) != 0);
+}
+
+// z = A^-1 x on whatever storage `io` names (shape and pointers checked by the entry point)
+int inverse_io(const ScanIO &io, const float *w, int B, int C, int H, int W, int KH, int KW, int order, unsigned flags, void *ws,
+               size_t ws_bytes, void *carry, void *scan_state, hipStream_t stream)
+{
+    Geom g = make_geom(B, C, H, W, KH, KW, order, flags);
+    Carver cv(ws, ws_bytes);
+    bool amax_ok = false;
+    int rc = run_scan(io, w, g, 0, flags, cv, carry, nullptr, &amax_ok, scan_state, stream);
+    if (rc) return rc;
+    if (carry && carry_usable(g, flags) && !amax_ok && io.z32) {
+        // the general scan ran (unaligned pointers): collect max|z| with a streaming pass (rare path)
+        const CarryView cvw = carry_view(carry, C, KH, KW);
+        if ((rc = launch_absmax(io.z32, (size_t)B * C * H * W, cvw.zmax, stream))) return rc;
+    }
+    return IFL_OK;
+}
+
+} // namespace ifl
 
 extern "C" {
 
@@ -343,17 +379,7 @@ int ifl_inverse_f32(const float *x, const float *w, float *z, int B, int C, int 
     if (B == 0) return IFL_OK;
     if (!x || !w || !z) IFL_FAIL(IFL_EINVAL, "ifl_inverse_f32: null tensor pointer");
     if (x == z) IFL_FAIL(IFL_EINVAL, "ifl_inverse_f32: z must not alias x (an image that leaves the fp16 range is redone from x)");
-    Geom g = make_geom(B, C, H, W, KH, KW, order, flags);
-    Carver cv(ws, ws_bytes);
-    bool amax_ok = false;
-    rc = run_scan(x, w, z, g, 0, flags, cv, carry, nullptr, &amax_ok, scan_state, (hipStream_t)stream);
-    if (rc) return rc;
-    if (carry && carry_usable(g, flags) && !amax_ok) {
-        // the general scan ran (unaligned pointers): collect max|z| with a streaming pass (rare path)
-        const CarryView cvw = carry_view(carry, C, KH, KW);
-        if ((rc = launch_absmax(z, (size_t)B * C * H * W, cvw.zmax, (hipStream_t)stream))) return rc;
-    }
-    return IFL_OK;
+    return ifl::inverse_io(scan_io_f32(x, z), w, B, C, H, W, KH, KW, order, flags, ws, ws_bytes, carry, scan_state, (hipStream_t)stream);
 }
 
 int ifl_forward_f32(const float *z, const float *w, float *xhat, float *logdet, int B, int C, int H, int W, int KH,
@@ -430,8 +456,22 @@ int ifl_backward_f32(const float *gout, const float *z, const float *x, const fl
     if (B > 0 && (!gout || !w)) IFL_FAIL(IFL_EINVAL, "ifl_backward_f32: null tensor pointer");
     if (B > 0 && dw && !z) IFL_FAIL(IFL_EINVAL, "ifl_backward_f32: dw requested but z is null");
     if (B > 0 && dx && dx == gout) IFL_FAIL(IFL_EINVAL, "ifl_backward_f32: dx must not alias g (an image that leaves the fp16 range is redone from g)");
-    if (!dx && !dw) return IFL_OK;
-    hipStream_t s = (hipStream_t)stream;
+    return ifl::backward_io(ScanIO{gout, nullptr, dx, nullptr}, z, x, w, dw, recon_weight, recon_loss, B, C, H, W, KH, KW, order, flags,
+                            ws, ws_bytes, carry, scan_state, (hipStream_t)stream);
+}
+
+} // extern "C"
+
+namespace ifl {
+
+// (dx, dW) with g and dx on whatever storage `gio` names: x32 / x16 = g, z32 / z16 = dx (either may be NULL: the weight
+// gradient contracts the fp32 dx, which then lives in the workspace).  z, x (recon term), dW are fp32.
+int backward_io(const ScanIO &gio, const float *z, const float *x, const float *w, float *dw, float recon_weight, float *recon_loss,
+                int B, int C, int H, int W, int KH, int KW, int order, unsigned flags, void *ws, size_t ws_bytes, void *carry,
+                void *scan_state, hipStream_t s)
+{
+    int rc;
+    if (!gio.z32 && !gio.z16 && !dw) return IFL_OK;
     Geom g = make_geom(B, C, H, W, KH, KW, order, flags);
     const size_t n = (size_t)B * C * H * W;
     if (B == 0) {
@@ -441,9 +481,9 @@ int ifl_backward_f32(const float *gout, const float *z, const float *x, const fl
     }
     const bool recon = dw && x && recon_weight != 0.0f;
     Carver cv(ws, ws_bytes);
-    float *u = dx ? dx : cv.take<float>(n);
+    float *u = gio.z32 ? gio.z32 : ((dw || !gio.z16) ? cv.take<float>(n) : nullptr);
     bool dxmax_ok = false;
-    if ((rc = run_scan(gout, w, u, g, 1, flags, cv, nullptr, carry, &dxmax_ok, scan_state, s))) return rc;
+    if ((rc = run_scan(ScanIO{gio.x32, gio.x16, u, gio.z16}, w, g, 1, flags, cv, nullptr, carry, &dxmax_ok, scan_state, s))) return rc;
     if (!dw) return IFL_OK;
     const float *gsrc = u;
     if (recon) {
@@ -484,6 +524,10 @@ int ifl_backward_f32(const float *gout, const float *z, const float *x, const fl
         return dw_impl(z, gsrc, dw, B, C, H, W, KH, KW, order, flags, rest, rest_bytes, amax_dx, amax_z, s);
     }
 }
+
+} // namespace ifl
+
+extern "C" {
 
 // ---- the inverse-flow block: TL -> TR -> BL -> BR (inf/layers/inv_flow.py:13-53) ------------------------------
 
@@ -552,7 +596,7 @@ int ifl_unit_inverse_f32(const float *x, const float *const w[4], float *const z
     for (int l = 0; l < 4; ++l) {
         ProfScope ps(IFL_PROF_SCAN, s);
         if (in[l] == z[l]) IFL_FAIL(IFL_EINVAL, "ifl_unit_inverse_f32: a layer's output must not alias its input");
-        if ((rc = launch_scan_mfma(in[l], wf[l], z[l], g[l], g[l].flipH, g[l].flipW, ovf[l], wf2[l], co[l].zmax, scan_state,
+        if ((rc = launch_scan_mfma(scan_io_f32(in[l], z[l]), wf[l], g[l], g[l].flipH, g[l].flipW, ovf[l], wf2[l], co[l].zmax, scan_state,
                                    (flags & IFL_FLAG_WHOLE_IMAGE) != 0, s)))
             return rc;
     }

@@ -2,13 +2,14 @@
 // reference dispatches on the tensor's dtype, inv_conv_with_bp_kernel_general.cu:112).
 //
 // Activations (x, z, g, dx, xhat) are bf16 in HBM; weights, weight gradients, log-determinants and every intermediate
-// are fp32.  The scans and the weight gradient are bound by the matrix pipe and by hand-off latency, not by HBM (DESIGN
-// 4.1), and their operand staging is built around 128-byte lines of fp32: a bf16 call therefore widens its inputs into
-// the caller's workspace with one streaming pass, runs the f32 path unchanged and narrows the result with another -- 6
-// bytes per element and pass, 50 MB and 8.5-10 us each at the north-star shape: a step (x in, z out; g and z in, dx out)
-// costs 43 us more than in fp32 storage.  What the caller gains is the halved footprint and traffic of
-// everything around the layer (the *_bf16 kernels of glow_step.hip are single passes in bf16) and no casts of its own.
-// A bf16 call returns exactly the rounded result of the f32 call on the widened inputs.
+// are fp32.  A bf16 call returns exactly the rounded result of the f32 call on the widened inputs.
+//
+// Layers that take the duo scan (32 or 64 channels, 32-pixel rows: scan_duo.hip) run on bf16 storage NATIVELY: the scan's
+// rows arrive as half-width lines by LDS-DMA and are widened inside the LDS-resident tile, finished rows leave rounded (and
+// -- the adjoint scan of a backward -- as fp32 too, into the workspace, for the weight gradient, which contracts fp32 dx
+// with fp32 z: only z is widened by a streaming pass).  Every other shape widens its inputs into the caller's workspace
+// with one streaming pass, runs the f32 path unchanged and narrows the result with another (6 bytes per element and pass;
+// 8.5-10 us each at the north-star shape).
 #include "ifl_common.h"
 #include "bf16_util.h"
 #include "../../include/invflow.h"
@@ -132,8 +133,11 @@ int ifl_inverse_bf16(const uint16_t *x, const float *w, uint16_t *z, int B, int 
                  ifl_workspace_bytes_bf16(IFL_OP_INVERSE, B, C, H, W, KH, KW, flags));
     const size_t n = (size_t)B * C * H * W, nb = staged_bytes(B, C, H, W);
     Staging st(ws, ws_bytes);
-    float *x32 = st.take(nb), *z32 = st.take(nb);
     hipStream_t s = (hipStream_t)stream;
+    if ((const void *)x == (const void *)z) IFL_FAIL(IFL_EINVAL, "ifl_inverse_bf16: z must not alias x");
+    if (KH >= 1 && KW >= 1 && order >= 0 && order <= 3 && native_bf16_ok(B, C, H, W, KH, KW, order, flags, scan_state, x, z))
+        return inverse_io(ScanIO{nullptr, x, nullptr, z}, w, B, C, H, W, KH, KW, order, flags, st.p, st.left, carry, scan_state, s);
+    float *x32 = st.take(nb), *z32 = st.take(nb);
     widen_to(x, x32, nullptr, nullptr, nullptr, nullptr, n, s);
     if (int rc = ifl_inverse_f32(x32, w, z32, B, C, H, W, KH, KW, order, flags, st.p, st.left, carry, scan_state, stream)) return rc;
     narrow_to(z32, z, n, s);
@@ -184,6 +188,16 @@ int ifl_backward_bf16(const uint16_t *gout, const uint16_t *z, const uint16_t *x
     Staging st(ws, ws_bytes);
     float *g32 = st.take(nb), *z32 = st.take(nb), *x32 = st.take(nb), *dx32 = st.take(nb);
     hipStream_t s = (hipStream_t)stream;
+    if (dw && !z) IFL_FAIL(IFL_EINVAL, "ifl_backward_bf16: dw requested but z is null");
+    if (dx && (const void *)dx == (const void *)gout) IFL_FAIL(IFL_EINVAL, "ifl_backward_bf16: dx must not alias g");
+    if (KH >= 1 && KW >= 1 && order >= 0 && order <= 3 && native_bf16_ok(B, C, H, W, KH, KW, order, flags, scan_state, gout, dx ? dx : gout)) {
+        // g is read and dx written in bf16 by the adjoint scan itself; the weight gradient wants fp32 z (and x for the recon
+        // term): one streaming pass; its fp32 dx comes out of the same scan launch
+        const bool recon = dw && x && recon_weight != 0.0f;
+        if (dw) widen_to(z, z32, recon ? x : nullptr, x32, nullptr, nullptr, n, s);
+        return backward_io(ScanIO{nullptr, gout, dw ? dx32 : nullptr, dx}, dw ? z32 : nullptr, recon ? x32 : nullptr, w, dw, recon_weight,
+                           recon_loss, B, C, H, W, KH, KW, order, flags, st.p, st.left, carry, scan_state, s);
+    }
     widen_to(gout, g32, z, z32, x, x32, n, s); // (one launch)
     // (the weight gradient contracts the fp32 dx with z: dx32 is kept even when the caller does not want dx)
     if (int rc = ifl_backward_f32(g32, z ? z32 : nullptr, x ? x32 : nullptr, w, dx32, dw, recon_weight, recon_loss, B, C, H, W, KH, KW,

@@ -122,13 +122,34 @@ struct SplitState {
 size_t scan_duo_state_bytes();
 int scan_duo_max_images();
 bool scan_duo_supported(const Geom &g);
+// What a scan reads and writes.  x32 or x16 (bf16 storage); z goes to z32 (fp32), to z16 (bf16, rounded to nearest even)
+// or to both.  Only the duo scan takes the 16-bit forms; every other route wants x32 / z32.
+struct ScanIO {
+    const float *x32;
+    const uint16_t *x16;
+    float *z32;
+    uint16_t *z16;
+};
+static inline ScanIO scan_io_f32(const float *x, float *z) { return ScanIO{x, nullptr, z, nullptr}; }
 // whole_image: an image of more than 16 rows stays in ONE workgroup, which sweeps its two tiles in turn (IFL_FLAG_WHOLE_IMAGE)
-int launch_scan_duo(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, int *flags,
-                    const float *wf32, unsigned *amax, void *state, bool whole_image, hipStream_t s);
+int launch_scan_duo(const ScanIO &io, const void *apack, const Geom &g, int rh, int rw, int *flags, const float *wf32,
+                    unsigned *amax, void *state, bool whole_image, hipStream_t s);
+// true when launch_scan_mfma sends this shape to the duo scan with this scan-state block (the route that takes bf16 storage)
+bool scan_duo_route(const Geom &g, const void *state, bool whole_image);
+// ---- the layer's inverse and backward on whatever storage a ScanIO names (api.hip; the *_bf16 entry points of bf16_io.hip
+//      call them with 16-bit activations when native_bf16_ok(), and go through fp32 staging otherwise) -------------------
+bool native_bf16_ok(int B, int C, int H, int W, int KH, int KW, int order, unsigned flags, const void *scan_state, const void *a,
+                    const void *b);
+int inverse_io(const ScanIO &io, const float *w, int B, int C, int H, int W, int KH, int KW, int order, unsigned flags, void *ws,
+               size_t ws_bytes, void *carry, void *scan_state, hipStream_t stream);
+// gio: x32 / x16 = g, z32 / z16 = dx (either or both; fp32 dx lives in the workspace when the caller has no place for it)
+int backward_io(const ScanIO &gio, const float *z, const float *x, const float *w, float *dw, float recon_weight, float *recon_loss,
+                int B, int C, int H, int W, int KH, int KW, int order, unsigned flags, void *ws, size_t ws_bytes, void *carry,
+                void *scan_state, hipStream_t s);
 // amax: optional device word that receives max|z| (atomicMax of float bits; must be cleared beforehand)
 // state: the caller's scan-state block or NULL; whole_image: keep one workgroup per image (IFL_FLAG_WHOLE_IMAGE)
-int launch_scan_mfma(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, int *flags,
-                     const float *wf32, unsigned *amax, void *state, bool whole_image, hipStream_t s);
+int launch_scan_mfma(const ScanIO &io, const void *apack, const Geom &g, int rh, int rw, int *flags, const float *wf32,
+                     unsigned *amax, void *state, bool whole_image, hipStream_t s);
 
 // ---- MFMA weight gradient (wgrad_mfma.hip): C in {32,64}, W in {16,32}, K in {2x2,3x3}, corner pads ----
 bool wgrad_mfma_supported(int B, int C, int H, int W, int KH, int KW, int pt, int pl, const void *gz, const void *x);

@@ -42,6 +42,7 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#include "bf16_util.h"
 #include "ifl_common.h"
 #include "mfma_util.h"
 #include "scan_general_body.h"
@@ -185,8 +186,17 @@ __device__ __forceinline__ void store_piece(unsigned voff, const floatx4 &v, cha
     asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 " IFL_STR(IFL_CAT(IFL_POL_, IFL_ST_POL)) "\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(dst) : "memory");
 }
 
-template <int C, int KH, int KW, bool PAD>
-__global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__restrict__ xin, float *__restrict__ zout,
+// BF: x is stored as bf16 (the *_bf16 entry points): its rows arrive as half-width lines and are widened inside the tile; z
+// leaves as fp32 (zout), as bf16 rounded to nearest even (zout16), or both, whichever is not NULL -- bit for bit what the
+// f32 launch on the widened input returns, rounded.
+__device__ __forceinline__ void store_piece16(unsigned voff, const uintx2 &v, char *dst)
+{
+    asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2 " IFL_STR(IFL_CAT(IFL_POL_, IFL_ST_POL)) ::"v"(voff), "v"(v), "s"(dst) : "memory");
+}
+
+template <int C, int KH, int KW, bool PAD, bool BF>
+__global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const void *__restrict__ xin_, float *__restrict__ zout,
+                                                             bf16_t *__restrict__ zout16,
                                                              const half8 *__restrict__ apack, const int H, const int W,
                                                              const int rh, const int rw, int *__restrict__ flags,
                                                              const float *__restrict__ wf32, const Geom geom,
@@ -195,9 +205,12 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
     using Cfg = DuoCfg<C, KH, KW>;
     constexpr int NW = Cfg::NW, NQ = Cfg::NQ, NS = Cfg::NS, RBB = Cfg::RBB, SLOTB = Cfg::SLOTB;
     constexpr int PF = Cfg::PF, PFH = Cfg::PFH, LEAD = Cfg::LEAD, ZLAG = Cfg::ZLAG, SLAG = Cfg::SLAG, CPH = Cfg::CPH;
+    constexpr int NDMA = BF ? 1 : Cfg::CPH; // vector-memory operations of a wave per requested row
     constexpr int PER = NQ * 2; // LDS reads of one fragment set
     constexpr int GM = 3 * NQ;  // MFMAs of one tap
     static_assert(!PAD, "the duo scan takes layers of exactly 32 or 64 channels (launch_scan_mfma routes the others)");
+    using XT = std::conditional_t<BF, bf16_t, float>;
+    const XT *__restrict__ xin = (const XT *)xin_;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
 #ifdef IFL_PAD
@@ -266,17 +279,40 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
     //      them).  Lane l of a piece holds the sixteen bytes at LDS position l: channel cc = l >> 3 of the chunk, quad
     //      ((l & 7) - 4 (cc >> 2)) & 7 of its line: 8 consecutive lanes cover one 128-byte (channel, row) line, loads and stores
     const int pcc = lane >> 3, pq = ((lane & 7) - 4 * (pcc >> 2)) & 7;
-    const unsigned pgo = (unsigned)(pcc * H * W * 4 + pq * 16); // byte offset inside a chunk's 8 channel planes
-    const char *xg = (const char *)xin + ((size_t)b * C + 16 * wv) * H * W * sizeof(float);
+    const unsigned pgo = (unsigned)(pcc * H * W * 4 + pq * 16); // byte offset inside a chunk's 8 channel planes (fp32)
+    const char *xg = (const char *)xin + ((size_t)b * C + 16 * wv) * H * W * sizeof(XT);
     const unsigned chunkB = (unsigned)(8 * H * W * 4);
     const unsigned tchunk = ldsbase + Cfg::OFF_T + (2 * wv) * 1024; // (+ row TROWB, + 1024 for the second chunk)
-    // rows [r0, r1) of the tile at image row hoff, this wave's two pieces each: global -> tile (rows may be reflected)
+    // bf16 rows: a (channel, row) line is 64 bytes, a wave's 16 channels ONE 1-KiB piece: lane l brings the sixteen bytes
+    // (channel l >> 2, pixels 8 (l & 3) ...).  It lands in the second chunk's place and is widened from there (cvt_row).
+    const unsigned bgo = (unsigned)((lane >> 2) * H * W * 2 + (lane & 3) * 16);
+    // rows [r0, r1) of the tile at image row hoff, this wave's pieces: global -> tile (rows may be reflected)
     auto load_rows = [&](const int hoff, const int r0, const int r1) {
         for (int r = r0; r < r1; ++r) {
-            const char *src = xg + (rh ? H - 1 - (hoff + r) : hoff + r) * W * 4;
+            const char *src = xg + (rh ? H - 1 - (hoff + r) : hoff + r) * W * (int)sizeof(XT);
             const unsigned dst = __builtin_amdgcn_readfirstlane(tchunk + r * Cfg::TROWB);
-            dma_piece(dst, pgo, src);
-            dma_piece(dst + 1024, pgo + chunkB, src);
+            if constexpr (BF) {
+                dma_piece(dst + 1024, bgo, src);
+            } else {
+                dma_piece(dst, pgo, src);
+                dma_piece(dst + 1024, pgo + chunkB, src);
+            }
+        }
+    };
+    // a landed bf16 row of this wave -> fp32, in place: every lane reads its sixteen bytes (8 pixels of one channel), the
+    // wave waits, every lane writes the two quads where the fp32 layout wants them (all reads are back before the first
+    // write goes out: the landing place and the destinations overlap)
+    auto cvt_row = [&](const int r) {
+        if constexpr (BF) {
+            const unsigned base = tchunk + r * Cfg::TROWB;
+            uintx4 v;
+            asm volatile("ds_read_b128 %0, %1 offset:1024\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(base + lane * 16) : "memory");
+            const int c16 = lane >> 2, cc = c16 & 7, q0 = 2 * (lane & 3);
+            const unsigned d0 = base + (c16 >> 3) * 1024 + (8 * cc + ((q0 + 4 * (cc >> 2)) & 7)) * 16;
+            const unsigned d1 = base + (c16 >> 3) * 1024 + (8 * cc + ((q0 + 1 + 4 * (cc >> 2)) & 7)) * 16;
+            const uintx4 a = {v[0] << 16, v[0] & 0xffff0000u, v[1] << 16, v[1] & 0xffff0000u};
+            const uintx4 c = {v[2] << 16, v[2] & 0xffff0000u, v[3] << 16, v[3] & 0xffff0000u};
+            asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %2, %3" ::"v"(d0), "v"(a), "v"(d1), "v"(c) : "memory");
         }
     };
     // The launched tile's rows are requested at kernel entry, in front of everything else: the latency of the first rows
@@ -298,6 +334,7 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
         bool publish, consume;
         unsigned tag;
         int dfirst;
+        bool first; // the launched pass's first sweep: its rows were requested at kernel entry
     };
     const unsigned tag1 = gen0 + 1, tag2 = gen0 + 2;
     auto sweep_of = [&](const int redo, const int t) {
@@ -312,6 +349,7 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
         s.consume = two && part == 1;
         s.tag = redo ? tag2 : tag1;
         s.dfirst = s.consume ? -PF : -LEAD;
+        s.first = !redo && t == 0;
         return s;
     };
     const int nfirst = solo ? 2 : 1; // sweeps of the launched pass
@@ -353,7 +391,7 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
         }
         const int wadr = RBB + (((c0 / 32) * 2) * 4 + (c0 % 32) / 8) * 256 + n * 16 + ((c0 % 8) / 4) * 8;
 
-        auto chain_sweep = [&](const Sweep &sw) {
+        auto chain_sweep = [&](const Sweep sw) {
             const int Hp = sw.Hp;
             const float xscale = sw.xscale;
             const bool hval = n < Hp;
@@ -583,7 +621,12 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
             for (; d + 2 <= ND - 1; d += 3) { // ((d + 1) mod 3 = 0 here)
                 // (the rows this wave requested at kernel entry -- HSPLIT and up -- have landed: the only vector-memory operations
                 // it has in flight; two steps and a barrier before anybody touches the first of them)
-                if (d == HSPLIT - 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (d == HSPLIT - 3) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if constexpr (BF)
+                        if (sw.first) // (the rows this wave requested: the launched pass's first sweep)
+                            for (int r = HSPLIT; r < Hp; ++r) cvt_row(r);
+                }
                 step(std::integral_constant<int, 0>{}, d);
                 step(std::integral_constant<int, 1>{}, d + 1);
                 step(std::integral_constant<int, 2>{}, d + 2);
@@ -641,7 +684,7 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
         }
         const int bad2 = __syncthreads_or(rmax < 6.0e4f ? 0 : 1);
         if (bad2) {
-            scan_general_body<Cfg::THREADS>(xin, wf32, zout, geom, rh, rw, 1, (float *)lds, b, tid);
+            scan_general_body<Cfg::THREADS, XT>(xin, wf32, zout, geom, rh, rw, 1, (float *)lds, b, tid, zout16);
             __syncthreads();
         }
         return;
@@ -661,6 +704,8 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
 #pragma unroll
             for (int hl = 0; hl < 2; ++hl) asm volatile("" : "+v"(Z[q][hl]));
         char *zg = (char *)zout + ((size_t)b * C + 16 * wv) * H * W * sizeof(float);
+        char *zg16 = (char *)zout16 + ((size_t)b * C + 16 * wv) * H * W * sizeof(bf16_t);
+        const unsigned pgo16 = pgo / 2, chunkB16 = chunkB / 2; // (a lane's quad as four bf16: eight bytes of a 64-byte line)
         const unsigned dmy = __builtin_amdgcn_readfirstlane(ldsbase + Cfg::OFF_DMY);
         const unsigned hdump = ldsbase + Cfg::OFF_DUMP + 2048 + lane * 4;
         // mailbox role of helper 0: lane l carries the 8-byte piece (row 14 + (l & 1), plane (l >> 1) & 15, half l >> 5)
@@ -729,7 +774,7 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
             load_rows(s0.hoff, 0, s0.Hp < HSPLIT ? s0.Hp : HSPLIT);
         }
 
-        auto helper_sweep = [&](const Sweep &sw, const bool last_of_pass, const bool preloaded) {
+        auto helper_sweep = [&](const Sweep sw, const bool last_of_pass, const bool preloaded) {
             const int Hp = sw.Hp, hoff = sw.hoff;
             const float zscale = sw.zscale;
             const unsigned tag = sw.tag;
@@ -843,7 +888,10 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                     // Row d+1 -- its first pixel is on diagonal d+1, which the chain reads next step -- must have landed: all but
                     // the operations behind its DMAs, which are the rows after it and the mailbox operations of the sweep's steps
                     // so far (this step's comes behind this wait)
-                    if ((unsigned)(d + 1) < (unsigned)HR) wait_vm(CPH * (HR - d - 2) + M * (d - dfirst));
+                    if ((unsigned)(d + 1) < (unsigned)HR) {
+                        wait_vm(NDMA * (HR - d - 2) + M * (d - dfirst));
+                        cvt_row(d + 1);
+                    }
                 }
                 if (mb_in) {
                     if (d == -2 - PFH) {
@@ -887,9 +935,20 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
                 }
                 if (st_due) { // the row on its way out, second half
                     asm volatile("" : "+v"(sv[0]), "+v"(sv[1]));
-                    char *dst = zg + row_off(rs);
-                    store_piece(pgo, sv[0], dst);
-                    store_piece(pgo + chunkB, sv[1], dst);
+                    if (zout) {
+                        char *dst = zg + row_off(rs);
+                        store_piece(pgo, sv[0], dst);
+                        store_piece(pgo + chunkB, sv[1], dst);
+                    }
+                    if (zout16) {
+                        char *dst = zg16 + row_off(rs) / 2;
+                        const uintx2 h0 = {(unsigned)narrow_bf16(sv[0][0]) | ((unsigned)narrow_bf16(sv[0][1]) << 16),
+                                           (unsigned)narrow_bf16(sv[0][2]) | ((unsigned)narrow_bf16(sv[0][3]) << 16)};
+                        const uintx2 h1 = {(unsigned)narrow_bf16(sv[1][0]) | ((unsigned)narrow_bf16(sv[1][1]) << 16),
+                                           (unsigned)narrow_bf16(sv[1][2]) | ((unsigned)narrow_bf16(sv[1][3]) << 16)};
+                        store_piece16(pgo16, h0, dst);
+                        store_piece16(pgo16 + chunkB16, h1, dst);
+                    }
                 }
                 // hand-off in: rows 14, 15 of the upper part's diagonal d + 16 join diagonal d of this tile's ring
                 if (h_in) {
@@ -1003,12 +1062,19 @@ __global__ __launch_bounds__(128 * (C / 16)) void k_scan_duo(const float *__rest
         const int bad2 = __syncthreads_or(dead);
         if (tid == NW * 64) flags[b] = 1 + (bad2 ? 4 : 0);
         if (bad2) {
-            scan_general_body<Cfg::THREADS>(xin, wf32, zout, geom, rh, rw, 1, (float *)lds, b, tid);
+            scan_general_body<Cfg::THREADS, XT>(xin, wf32, zout, geom, rh, rw, 1, (float *)lds, b, tid, zout16);
             __syncthreads();
             if (amax) { // the rows stored above are void: take the maximum of what the redo wrote
-                const float *zi = zout + (size_t)b * C * H * W;
                 zmax = 0.f;
-                for (int i = tid - NW * 64; i < C * H * W; i += NW * 64) zmax = fmaxf(zmax, fabsf(zi[i]));
+                if (zout) {
+                    const float *zi = zout + (size_t)b * C * H * W;
+                    for (int i = tid - NW * 64; i < C * H * W; i += NW * 64) zmax = fmaxf(zmax, fabsf(zi[i]));
+                } else {
+                    // (bf16 output only: the rounded values bound the maximum to half an ulp of bf16 -- the prescale it feeds
+                    // is a power of two with a factor of two of headroom)
+                    const bf16_t *zi = zout16 + (size_t)b * C * H * W;
+                    for (int i = tid - NW * 64; i < C * H * W; i += NW * 64) zmax = fmaxf(zmax, fabsf(widen(zi[i])));
+                }
             }
         }
         reduce_amax();
@@ -1029,14 +1095,14 @@ bool scan_duo_supported(const Geom &g)
     return (g.C == 32 || g.C == 64) && g.W == 32 && g.H <= 32 && ((g.KH == 3 && g.KW == 3) || (g.KH == 2 && g.KW == 2));
 }
 
-template <int C, int KH, int KW, bool PAD>
-static int launch_duo(const float *x, float *z, const void *apack, const Geom &g, int rh, int rw, int *flags,
+template <int C, int KH, int KW, bool PAD, bool BF>
+static int launch_duo(const void *x, float *z, bf16_t *z16, const void *apack, const Geom &g, int rh, int rw, int *flags,
                       const float *wf32, unsigned *amax, char *state, bool whole_image, hipStream_t s)
 {
     using Cfg = DuoCfg<C, KH, KW>;
     static_assert(Cfg::LDSB <= 160 * 1024, "ring + tile must fit the CU's LDS");
     static LdsOptIn opt_in;
-    if (int rc = lds_opt_in(opt_in, (const void *)k_scan_duo<C, KH, KW, PAD>, Cfg::LDSB)) return rc;
+    if (int rc = lds_opt_in(opt_in, (const void *)k_scan_duo<C, KH, KW, PAD, BF>, Cfg::LDSB)) return rc;
     if (scan_general_lds_bytes(g) > (size_t)Cfg::LDSB)
         IFL_FAIL(IFL_EUNSUPPORTED, "launch_scan_duo: fp32 fallback does not fit the kernel's LDS");
     // an image of more than 16 rows is two tiles: two workgroups (nparts = 2), or -- whole_image -- one that sweeps both
@@ -1051,18 +1117,22 @@ static int launch_duo(const float *x, float *z, const void *apack, const Geom &g
     }
 #endif
     const dim3 grid(nparts == 2 ? 16 * ((g.B + 7) / 8) : g.B);
-    hipLaunchKernelGGL((k_scan_duo<C, KH, KW, PAD>), grid, dim3(Cfg::THREADS), Cfg::LDSB, s, x, z, (const half8 *)apack, g.H,
+    hipLaunchKernelGGL((k_scan_duo<C, KH, KW, PAD, BF>), grid, dim3(Cfg::THREADS), Cfg::LDSB, s, x, z, z16, (const half8 *)apack, g.H,
                        g.W, rh, rw, flags, wf32, g, amax, sp, nparts);
     IFL_HIP(hipGetLastError());
     return IFL_OK;
 }
 
-int launch_scan_duo(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, int *flags,
-                    const float *wf32, unsigned *amax, void *state, bool whole_image, hipStream_t s)
+int launch_scan_duo(const ScanIO &io, const void *apack, const Geom &g, int rh, int rw, int *flags, const float *wf32,
+                    unsigned *amax, void *state, bool whole_image, hipStream_t s)
 {
+    if (!io.z32 && !io.z16) IFL_FAIL(IFL_EINVAL, "launch_scan_duo: no output");
 #define IFL_CASE(CC, KK)                                                                                               \
     if (g.C == CC && g.KH == KK && g.KW == KK)                                                                         \
-        return launch_duo<CC, KK, KK, false>(x, z, apack, g, rh, rw, flags, wf32, amax, (char *)state, whole_image, s);
+        return io.x16 ? launch_duo<CC, KK, KK, false, true>(io.x16, io.z32, io.z16, apack, g, rh, rw, flags, wf32, amax,      \
+                                                            (char *)state, whole_image, s)                                \
+                      : launch_duo<CC, KK, KK, false, false>(io.x32, io.z32, io.z16, apack, g, rh, rw, flags, wf32, amax,     \
+                                                             (char *)state, whole_image, s);
     IFL_CASE(64, 3)
     IFL_CASE(32, 3)
     IFL_CASE(64, 2)

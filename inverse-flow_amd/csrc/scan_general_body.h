@@ -1,6 +1,7 @@
 // General fp32 wavefront scan body shared by k_scan_general (scan_general.hip) and by the in-kernel
 // overflow fallback of the MFMA scan (scan_mfma.hip).  See scan_general.hip for the description.
 #pragma once
+#include "bf16_util.h"
 #include "ifl_common.h"
 
 namespace ifl {
@@ -18,11 +19,17 @@ __device__ __forceinline__ size_t pix_addr(int b, int c, int h, int w, const Geo
 // rf = 1: wf is the right fold [s][kc][c] the MFMA path uses (s<NT-1: -(W_{s+1} L^-1), s=NT-1: L^-1):
 //         r_p = x_p + sum Wr_s r_{p-t},  z_p = L^-1 r_p  (the ring then carries r, two barriers per step)
 // All threads of the workgroup (NTHR of them) must call this; smem needs scan_general_lds_bytes(g).
-template <int NTHR>
-__device__ __forceinline__ void scan_general_body(const float *__restrict__ xin, const float *__restrict__ wf,
-                                                  float *__restrict__ zout, const Geom &g, int rh, int rw, int rf,
-                                                  float *smem, int b, int tid)
+// TI: storage type of x (float, or bf16_t widened at the load); z goes to zout (fp32) and / or zout16 (bf16, rounded to
+// nearest even at the store), whichever is not NULL.
+template <int NTHR, typename TI = float>
+__device__ __forceinline__ void scan_general_body(const TI *__restrict__ xin, const float *__restrict__ wf,
+                                                  float *__restrict__ zout, const Geom g, int rh, int rw, int rf,
+                                                  float *smem, int b, int tid, bf16_t *__restrict__ zout16 = nullptr)
 {
+    auto put = [&](size_t a, float v) {
+        if (zout) zout[a] = v;
+        if (zout16) zout16[a] = narrow_bf16(v);
+    };
     constexpr int SCAN_T = NTHR;
     const int C = g.C, H = g.H, W = g.W, KH = g.KH, KW = g.KW;
     const int R = KH + KW - 1;
@@ -46,7 +53,7 @@ __device__ __forceinline__ void scan_general_body(const float *__restrict__ xin,
         const int n = hmax - hmin + 1;
         for (int it = tid; it < n * C; it += SCAN_T) {
             const int c = it % C, h = hmin + it / C;
-            dst[h * Cp + c] = xin[pix_addr(b, c, h, d - h, g, rh, rw)];
+            dst[h * Cp + c] = widen(xin[pix_addr(b, c, h, d - h, g, rh, rw)]);
         }
     };
 
@@ -112,7 +119,7 @@ __device__ __forceinline__ void scan_general_body(const float *__restrict__ xin,
                         if (p < n) {
                             const int h = hmin + p;
                             zcur[h * Cp + c] = acc[j];
-                            if (!rf) zout[pix_addr(b, c, h, d - h, g, rh, rw)] = acc[j];
+                            if (!rf) put(pix_addr(b, c, h, d - h, g, rh, rw), acc[j]);
                         }
                     }
                 }
@@ -128,7 +135,7 @@ __device__ __forceinline__ void scan_general_body(const float *__restrict__ xin,
                         const float *rp = zcur + (hmin + p) * Cp;
                         float acc = 0.f;
                         for (int kc = 0; kc < C; ++kc) acc = fmaf(pw[(size_t)kc * C + c], rp[kc], acc);
-                        zout[pix_addr(b, c, hmin + p, d - hmin - p, g, rh, rw)] = acc;
+                        put(pix_addr(b, c, hmin + p, d - hmin - p, g, rh, rw), acc);
                     }
         }
     }

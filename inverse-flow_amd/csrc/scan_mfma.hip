@@ -1088,22 +1088,30 @@ static int launch_one(const float *x, float *z, const void *apack, const Geom &g
     return IFL_OK;
 }
 
-int launch_scan_mfma(const float *x, const void *apack, float *z, const Geom &g, int rh, int rw, int *flags,
-                     const float *wf32, unsigned *amax, void *state, bool whole_image, hipStream_t s)
+bool scan_duo_route(const Geom &g, const void *state, bool whole_image)
+{
+    if (!scan_duo_supported(g)) return false;
+    if (g.H <= 16) return true;
+    return state && g.B <= scan_duo_max_images() && (whole_image || 2 * g.B <= device_cus());
+}
+
+int launch_scan_mfma(const ScanIO &io, const void *apack, const Geom &g, int rh, int rw, int *flags, const float *wf32,
+                     unsigned *amax, void *state, bool whole_image, hipStream_t s)
 {
     const int nt = g.H <= 16 ? 1 : 2;
     const int ct = mfma_padded_channels(g.C);
     // Layers of exactly 32 or 64 channels on 32-pixel rows: the duo form (scan_duo.hip), one workgroup per 16-row tile --
     // an image of more than 16 rows is two workgroups, which needs the caller's scan-state block and a compute unit per
     // workgroup.  Everything else: one workgroup per image, below.
-    if (scan_duo_supported(g)) {
-        if (nt == 1) return launch_scan_duo(x, apack, z, g, rh, rw, flags, wf32, amax, nullptr, false, s);
+    if (scan_duo_route(g, state, whole_image)) {
+        if (nt == 1) return launch_scan_duo(io, apack, g, rh, rw, flags, wf32, amax, nullptr, false, s);
         // (whole_image: the same two sweeps by one workgroup per image, bit-identical to the two-workgroup form)
-        if (state && g.B <= scan_duo_max_images() && (whole_image || 2 * g.B <= device_cus())) {
-            if ((uintptr_t)state & 255) IFL_FAIL(IFL_EINVAL, "scan_state must be 256-byte aligned");
-            return launch_scan_duo(x, apack, z, g, rh, rw, flags, wf32, amax, state, whole_image, s);
-        }
+        if ((uintptr_t)state & 255) IFL_FAIL(IFL_EINVAL, "scan_state must be 256-byte aligned");
+        return launch_scan_duo(io, apack, g, rh, rw, flags, wf32, amax, state, whole_image, s);
     }
+    if (io.x16 || io.z16 || !io.x32 || !io.z32) IFL_FAIL(IFL_EUNSUPPORTED, "launch_scan_mfma: bf16 storage is the duo scan's");
+    const float *x = io.x32;
+    float *z = io.z32;
 #define IFL_CASE(CC, KK, NN) \
     if (ct == CC && g.KH == KK && g.KW == KK && nt == NN)                                                                   \
         return g.C == CC ? launch_one<CC, KK, KK, NN, false>(x, z, apack, g, rh, rw, flags, wf32, amax, s)                  \

@@ -49,12 +49,14 @@ def kernels(isa):
 def test_duo_register_budget_and_no_spills(isa):
     bodies, meta = kernels(isa)
     duo = {k: v for k, v in meta.items() if "k_scan_duo" in k}
-    assert len(duo) == 4  # C in {32, 64} x K in {2, 3}
+    assert len(duo) == 8  # C in {32, 64} x K in {2, 3} x storage in {f32, bf16}
     for name, m in duo.items():
-        assert m["spill"] == 0 and m["scratch"] == 0, (name, m)
+        # (no vector register is spilled and no instruction touches scratch memory; at the register limit the backend may
+        # still reserve a few dwords of frame for its scavenger -- 36 bytes in the 64-channel kernels -- which nothing uses)
+        assert m["spill"] == 0 and m["scratch"] <= 64, (name, m)
         if "ILi64E" in name:  # 512 threads: two waves per SIMD
             assert m["vgpr"] <= 256, (name, m)
-        assert not any("scratch_" in ln for ln in bodies[name]), name
+        assert not any(re.match(r"\s*(scratch_|buffer_(load|store))", ln) for ln in bodies[name]), name
 
 
 def _regs(tok):
@@ -109,7 +111,7 @@ def async_read_violations(lines):
 def test_no_register_is_touched_while_its_lds_read_is_in_flight(isa):
     bodies, _ = kernels(isa)
     duo = {k: v for k, v in bodies.items() if "k_scan_duo" in k}
-    assert len(duo) == 4
+    assert len(duo) == 8
     for name, lines in duo.items():
         n_reads = sum(1 for ln in lines if ln.strip().startswith("ds_read"))
         assert n_reads > 50, name  # (the walk looked at the right thing)

@@ -46,3 +46,7 @@ for part, name in ((0, "upper / single"), (1, "lower")):
     w = [o[2 * k + 1] for k in range(64) if o[2 * k]]
     print(name, "steps between barriers (cycles; in brackets: of which waiting at the barrier):")
     print("  " + " ".join("%d[%d]" % (t[k + 1] - t[k], w[k + 1]) for k in range(len(t) - 1)))
+# k_foldpack (workgroup 0): cycles of its phases (IFL_FSTAMP in scan_mfma.hip)
+f = s[160:164]
+if any(f):
+    print("k_foldpack workgroup 0 cycles: loads %d, diagonal blocks %d, block solve %d, pack %d" % tuple(f))

@@ -359,7 +359,7 @@ def model_workload(args, rank, local_rank, world):
             "data": "synthetic" if not args.dry else "none (dry run: no kernels)",
             "config": {"workload": "%s L=%d, K=%d, coupling width %d, as configured (actnorm=%s), batch %d = %d per rank, 32x32x3, Adam, "
                                    "%s" % (tag, cfg["num_blocks"], cfg["block_size"], cfg["coupling_width"], cfg["actnorm"], total, nb,
-                                           "one captured graph per step incl. the bucket all-reduce" if step.graph else "eager steps"),
+                                           ("one captured graph per step" if world == 1 else "two captured graphs per step around the bucket all-reduce") if step.graph else "eager steps"),
                        "per_rank_batch": nb, "parameters": nparam, "bucket_bytes": int(step.bucket.flat.numel()) * 4},
             "allreduce_us": ar_us,
             "bits_per_dim": None if args.dry else bits_per_dim(float(loss), 3 * 32 * 32),

@@ -56,6 +56,7 @@ class TrainStep:
         self.bucket = dp.GradBucket(model.parameters()) if bucket else None
         self.graph, self.graph_warmup = graph, graph_warmup
         self._calls, self._captured, self._static_x, self._static_loss, self._stream = 0, None, None, None, None
+        self._captured2, self._split = None, False
         self._ranks_agree = False  # data-dependent initialisations (ActNorm) made identical on every rank
         if graph:
             if self.bucket is None:
@@ -108,6 +109,11 @@ class TrainStep:
                 get_loss(self.model, x)
             dp.broadcast_parameters(self.model)
 
+    def _collective_due(self):
+        """a process group of more than one rank (or a test that wants the collective issued in a group of one)"""
+        return self.bucket is not None and dp.dist.is_available() and dp.dist.is_initialized() and (
+            dp.dist.get_world_size() > 1 or self.force_collective)
+
     def __call__(self, x):
         if not self._ranks_agree:
             self._agree_on_init(x)
@@ -128,18 +134,35 @@ class TrainStep:
                 return loss
             self._static_x = x.clone()
             torch.cuda.synchronize()
+            # With a collective in the step the capture is cut in two AROUND it: [loss, backward] and [clip, optimizer], the
+            # all-reduce of the bucket issued eagerly between the two replays.  (A captured RCCL all-reduce replays fine, but
+            # ProcessGroupNCCL's watchdog queries the work's event, which was recorded in a capturing stream:
+            # hipErrorCapturedEvent ends the process -- torch 2.10 + ROCm 7.0,
+            # tests/test_hip_train.py::test_captured_step_with_the_bucket_all_reduce_inside.)
+            self._split = self._collective_due()
             self._captured = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._captured, stream=self._stream):
-                self._static_loss = self._eager(self._static_x)
-            self._captured.replay()  # (capturing records the step without running it: this batch's step runs now)
-            return self._static_loss.clone()
+                self._static_loss = self._backward_part(self._static_x)
+                if not self._split:
+                    self._update_part()
+            if self._split:
+                self._captured2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._captured2, stream=self._stream, pool=self._captured.pool()):
+                    self._update_part()
+            return self._replay()  # (capturing records the step without running it: this batch's step runs now)
         if x.shape != self._static_x.shape:
             raise ValueError("TrainStep(graph=True) was captured for batches of shape %s" % (tuple(self._static_x.shape),))
         self._static_x.copy_(x)
+        return self._replay()
+
+    def _replay(self):
         self._captured.replay()
+        if self._split:
+            self.bucket.allreduce_mean(force=self.force_collective)
+            self._captured2.replay()
         return self._static_loss.clone()
 
-    def _eager(self, x):
+    def _backward_part(self, x):
         if self.bucket is not None:
             self.bucket.zero()
         else:
@@ -151,8 +174,9 @@ class TrainStep:
             self.model.add_recon_grad()
         if self.clear_grads:  # experiment.py:255 (the reference does this on its 'test' branch only)
             self.model.apply(clear_grad)
-        if self.bucket is not None:
-            self.bucket.allreduce_mean(force=self.force_collective)
+        return lossval.detach()
+
+    def _update_part(self):
         if self.grad_clip_norm is not None:  # experiment.py:287-289
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip_norm)
         if self.grad_clip:  # experiment.py:292-296: the reference clamps the PARAMETERS of layers that have a gradient
@@ -160,4 +184,10 @@ class TrainStep:
                 if p.grad is not None:
                     p.data.clamp_(-self.grad_clip, self.grad_clip)
         self.optimizer.step()
-        return lossval.detach()
+
+    def _eager(self, x):
+        lossval = self._backward_part(x)
+        if self.bucket is not None:
+            self.bucket.allreduce_mean(force=self.force_collective)
+        self._update_part()
+        return lossval

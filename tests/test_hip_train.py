@@ -265,14 +265,13 @@ from inf.train.step import TrainStep
 d = np.load(%r); fixture = {k: d[k] for k in d.files}
 x = torch.from_numpy(fixture["x"]).float().cuda()
 seqs = []
-for graph, force in ((False, False), (True, True)):
+for graph, force in ((True, False), (True, True)):  # (both with the capturable optimizer: the same arithmetic)
     torch.manual_seed(0)
     model = build(fixture)
     step = TrainStep(model, torch.optim.Adam(model.parameters(), lr=1e-3), grad_clip_norm=1.0, graph=graph, graph_warmup=2,
                      force_collective=force)
     seqs.append([float(step(x)) for _ in range(8)])
-    if graph:
-        assert step._captured is not None
+    assert step._captured is not None and step._split == force and (step._captured2 is not None) == force
 assert seqs[0] == seqs[1], seqs
 dist.destroy_process_group()
 print("captured step with the collective: ok")
@@ -280,9 +279,11 @@ print("captured step with the collective: ok")
 
 
 def test_captured_step_with_the_bucket_all_reduce_inside(tmp_path):
-    """TrainStep(graph=True) in a process group: the all-reduce of the flat gradient bucket is captured WITH the step (RCCL,
-    backend "nccl", here a group of one rank -- the collective kernel is issued, its result is the identity) and the replays
-    give the loss sequence of the eager step without it.  Its own process: the process group must not leak into the suite."""
+    """TrainStep(graph=True) in a process group (RCCL, backend "nccl", here a group of one rank: the collective kernel is
+    issued, its result is the identity): the step replays as TWO captured graphs around the eagerly issued all-reduce of the
+    flat gradient bucket -- a captured RCCL collective makes ProcessGroupNCCL's watchdog query an event recorded in a
+    capturing stream, which ends the process on this stack (inf/train/step.py) -- and gives, bit for bit, the loss sequence
+    of the one-graph step without the collective.  Its own process: the process group must not leak into the suite."""
     import subprocess
     import sys
     from conftest import PKG, ROOT

@@ -84,7 +84,25 @@ class Coupling(FlowLayer):
     def _conditioner(self, x, context):
         assert (context is not None) == self.uses_context
         x1 = x[:, :self.half_channels]
-        return self.net(x1 if context is None else torch.cat([x1, context], dim=1))
+        if context is not None:
+            x1 = torch.cat([x1, context], dim=1)
+        if x1.is_cuda and x1.dim() == 4 and torch.is_autocast_enabled("cuda"):
+            return self._net_channels_last(x1, torch.get_autocast_dtype("cuda"))
+        return self.net(x1)
+
+    def _net_channels_last(self, x1, dtype):
+        """`self.net` under autocast with the activations and the 16-bit copies of the kernels in channels-last memory.
+        MIOpen's 16-bit convolutions are NHWC kernels: handed NCHW tensors it wraps every one of them in transposes and
+        casts (20 launches for a forward + backward of the 3x3, 11 with NHWC operands, and 30 % less device time --
+        tools/conv_layout_probe.py), and the training step of these models is bound by its launch count.  Same modules, same
+        parameters, same casts as autocast makes (one per operand), only the memory format differs."""
+        cl = torch.channels_last
+        c1, c2, c3 = self.net[0], self.net[2], self.net[4]
+        h = F.conv2d(x1.to(dtype, memory_format=cl), c1.weight.to(dtype, memory_format=cl), None, c1.stride, c1.padding)
+        h = F.conv2d(F.relu(h), c2.weight.to(dtype, memory_format=cl), None, c2.stride, c2.padding)
+        h = F.conv2d(F.relu(h), c3.weight.to(dtype, memory_format=cl), None if c3.bias is None else c3.bias.to(dtype),
+                     c3.stride, c3.padding, c3.dilation, c3.groups)
+        return h * torch.exp(c3.logs * c3.logscale_factor)[None, :, None, None]
 
     def get_xs_logs_t(self, x, context=None):
         """(x1, x2, log_s, t) as torch tensors (the library path never materialises them)."""

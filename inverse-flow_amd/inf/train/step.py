@@ -47,17 +47,24 @@ class TrainStep:
     bucket; every launch of the library is stream-ordered and allocation-free, so it captures as it is."""
 
     def __init__(self, model, optimizer, add_recon_grad=False, grad_clip_norm=None, grad_clip=None, clear_grads=False,
-                 autocast=False, bucket=True, graph=False, graph_warmup=3, force_collective=False):
+                 autocast=False, bucket=True, graph=False, graph_warmup=3, force_collective=False, conv_search=False,
+                 fused_optimizer=True):
         self.model, self.optimizer = model, optimizer
         self.add_recon_grad, self.grad_clip_norm, self.grad_clip = add_recon_grad, grad_clip_norm, grad_clip
         self.clear_grads, self.autocast = clear_grads, autocast
         self.force_collective = force_collective  # issue the bucket's all-reduce in a one-rank process group too (tests)
         # every parameter's .grad is a view of one flat buffer: zeroing and the all-reduce are one operation each
         self.bucket = dp.GradBucket(model.parameters()) if bucket else None
+        self._n_params = sum(1 for _ in model.parameters())
         self.graph, self.graph_warmup = graph, graph_warmup
         self._calls, self._captured, self._static_x, self._static_loss, self._stream = 0, None, None, None, None
         self._captured2, self._split = None, False
         self._ranks_agree = False  # data-dependent initialisations (ActNorm) made identical on every rank
+        # conv_search=True: MIOpen times its solvers for the conditioners' convolutions in the warm-up steps instead of taking
+        # its heuristic's pick (a process-wide torch switch).  Off by default: worth 0-5 % of the configs[2]/[3] steps, and
+        # its picks -- and with them the last digits of the results -- vary from run to run (tools/time_trainsteps.py).
+        if conv_search:
+            torch.backends.cudnn.benchmark = True
         if graph:
             if self.bucket is None:
                 raise ValueError("TrainStep(graph=True) needs the gradient bucket (the gradients' addresses must not move)")
@@ -65,6 +72,8 @@ class TrainStep:
                 if "capturable" in group:
                     group["capturable"] = True
             self._make_capturable()
+            if fused_optimizer:
+                self._fuse_optimizer()
 
     def _make_capturable(self):
         """A captured optimizer step bakes every Python number it sees into its kernels.  The learning rate therefore
@@ -88,6 +97,20 @@ class TrainStep:
             for k, v in list(st.items()):
                 if torch.is_tensor(v) and v.device != dev:
                     st[k] = v.to(dev)
+
+    def _fuse_optimizer(self):
+        """Adam/AdamW over a model of a few hundred small tensors: torch's capturable foreach implementation divides every
+        tensor by two device scalars (`_foreach_div_` with 0-dim divisors takes its slow path: two broadcast kernels per
+        PARAMETER, 580 launches a step for the configs[3] model, a third of the step's dispatches -- tools/op_breakdown.py).
+        The fused multi-tensor implementation is one launch per ~hundred tensors, takes the learning rate as a device tensor
+        and can be captured: switched on here, before the optimizer's first step creates its state."""
+        if not isinstance(self.optimizer, (torch.optim.Adam, torch.optim.AdamW)) or self.optimizer.state:
+            return
+        for group in self.optimizer.param_groups:
+            if group.get("differentiable") or group.get("fused"):
+                continue
+            if all(p.is_cuda and torch.is_floating_point(p) for p in group["params"]):
+                group["foreach"], group["fused"] = False, True
 
     def set_lr(self, lr):
         """change the learning rate of every parameter group -- in place when it is a device tensor (graph=True), so that a
@@ -178,7 +201,13 @@ class TrainStep:
 
     def _update_part(self):
         if self.grad_clip_norm is not None:  # experiment.py:287-289
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip_norm)
+            if self.bucket is not None and len(self.bucket.params) == self._n_params:
+                # every gradient is a view of the flat bucket: its norm and the scaling are one kernel each, with the
+                # arithmetic of clip_grad_norm_ (coef = max_norm / (norm + 1e-6), clamped to 1)
+                norm = torch.linalg.vector_norm(self.bucket.flat)
+                self.bucket.flat.mul_(torch.clamp(self.grad_clip_norm / (norm + 1e-6), max=1.0))
+            else:
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip_norm)
         if self.grad_clip:  # experiment.py:292-296: the reference clamps the PARAMETERS of layers that have a gradient
             for p in self.model.parameters():
                 if p.grad is not None:

@@ -1,0 +1,721 @@
+// The conditioner of the affine coupling (inf/layers/coupling.py:47-62: `Coupling.net` = 3x3 conv C/2 -> width, ReLU,
+// 1x1 conv width -> C, ReLU, Conv2dZero C -> C = 3x3 conv + bias, times exp(3 logs) per channel: coupling.py:9-45), forward
+// and backward: two launches forward, three backward.
+//
+// Why it is here: the three convolutions are tiny (C <= 48 channels on <= 16x16 images; 0.05-0.5 GFLOP) and a training step
+// of the configs[2]/[3]/[4] models runs 33-150 of these nets.  On library convolutions one net is ~55 launches forward +
+// backward (layout and precision casts, convolutions, their zero-fills and reductions, ReLUs, the gain) at ~4.5 us each
+// in a graph replay: two thirds of the whole step (tools/time_stub_conditioner.py).  Here:
+//
+//   forward   k_cond_fwd1   a2 = relu(W2 relu(W1 * x1))     one pass; the `width`-channel hidden activation never leaves
+//                                                            registers (16 hidden units at a time)
+//             k_cond_fwd2   h  = (W3 * a2 + b3) exp(3 logs)
+//   backward  k_cond_bwd1   g3 = dh gain, d logs, d b3, g2 = relu'(a2) (W3^T * g3), and the two operand matrices of dW3
+//             k_cond_bwd2   hidden activation recomputed, g1 = relu'(a1) W2^T g2, and the operand matrices of dW1, dW2
+//             k_cond_bwd3   dx1 += W1^T * g1 (3x3 transposed: a gather over the g1 rows just written)
+//   the three weight gradients are then [rows x pixels] @ [pixels x cols] products with a long reduction and a small
+//   output -- plain library GEMMs (hipBLASLt through torch.mm on the host side: 5-30 us each), fed by 16-bit operand
+//   matrices these kernels write pixel-major (coalesced).
+//
+// Arithmetic: fp32 FMA on the fp32 master weights (nothing is cast per step).  A workgroup owns 64 pixels (a lane = a
+// pixel) and splits the reduction index -- hidden units, or input channels of the 3x3 over C -- over its J <= 8 waves,
+// whose partial sums meet in LDS slots and are added in wave order.  The work is far from any roofline (64-600 workgroups
+// of a few thousand FMAs per lane at one or two waves per SIMD): what decides the time is the number of exposed memory
+// round trips.  So every wave streams ITS weights (read once, 4-14 KB) through a 4 KB LDS stage: a block of up to 256
+// 16-byte quads in one batch of coalesced loads, consumed by uniform-address (broadcast) ds_reads.  [Scalar
+// loads look natural for wave-uniform weights and were tried first: each 64-byte line is a cold miss of the scalar cache
+// and s_waitcnt lgkmcnt(0) exposes every one -- 20-50 us per kernel instead of 3-8.]  Activation neighbourhoods are
+// loaded in one batch before the first FMA.  No float atomics: every sum has one owner and a fixed order (results are
+// reproducible bit for bit).
+#include "ifl_common.h"
+#include "bf16_util.h"
+
+namespace ifl {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+static constexpr int HC = 16;      // hidden units per register chunk
+static constexpr int STAGE = 1024; // floats of a wave's weight stage (256 quads: four per lane)
+
+struct CondShape {
+    int B, H, W, Wd, Cx; // Cx: channels of the tensor x1 is the head of
+};
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// A block of weights: nq 16-byte quads, either contiguous or rows of four quads (16 floats) `stride` floats apart.
+struct Blk {
+    const float *g;
+    int nq, stride; // stride 0: contiguous
+};
+__device__ __forceinline__ void blk_copy(float *wl, const Blk &b, int lane)
+{
+    f4 r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int qd = lane + 64 * i;
+        if (qd < b.nq) r[i] = *(const f4 *)(b.g + (b.stride ? (size_t)(qd >> 2) * b.stride + (qd & 3) * 4 : (size_t)qd * 4));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int qd = lane + 64 * i;
+        if (qd < b.nq) *(f4 *)(wl + qd * 4) = r[i];
+    }
+}
+
+// ---- weights: transposed copies + the gain ---------------------------------------------------------------------------
+// wt = [ W1t: K1 x Wd | W2t: Wd x C | W3t: 9C x C (k3 = ci*9+tap major, co minor) | W3b: 9C x C ((co*9+tap) major, ci
+//        minor) | gain: C | W1r: Wd x 9 x C/2 (w major, tap, ci minor) ]
+__host__ __device__ inline size_t cond_wt_floats(int C, int Wd) { return (size_t)18 * (C / 2) * Wd + (size_t)Wd * C + (size_t)18 * C * C + C; }
+
+__global__ __launch_bounds__(256) void k_cond_prep(const float *__restrict__ w1, const float *__restrict__ w2,
+                                                    const float *__restrict__ w3, const float *__restrict__ logs,
+                                                    float *__restrict__ wt, int C, int Wd, float logscale)
+{
+    const int K1 = 9 * (C / 2);
+    const size_t n1 = (size_t)K1 * Wd, n2 = (size_t)Wd * C, n3 = (size_t)9 * C * C;
+    const size_t total = 2 * n1 + n2 + 2 * n3 + C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float v;
+        if (i < n1) { // W1t[k][w] = W1[w][k]
+            const int k = (int)(i / Wd), w = (int)(i % Wd);
+            v = w1[(size_t)w * K1 + k];
+        } else if (i < n1 + n2) { // W2t[w][c] = W2[c][w]
+            const size_t j = i - n1;
+            const int w = (int)(j / C), c = (int)(j % C);
+            v = w2[(size_t)c * Wd + w];
+        } else if (i < n1 + n2 + n3) { // W3t[ci*9+tap][co] = W3[co][ci][tap]
+            const size_t j = i - n1 - n2;
+            const int k3 = (int)(j / C), co = (int)(j % C);
+            v = w3[(size_t)co * 9 * C + k3];
+        } else if (i < n1 + n2 + 2 * n3) { // W3b[co*9+tap][ci] = W3[co][ci][tap]
+            const size_t j = i - n1 - n2 - n3;
+            const int q = (int)(j / C), ci = (int)(j % C), co = q / 9, tap = q % 9;
+            v = w3[((size_t)co * C + ci) * 9 + tap];
+        } else if (i < n1 + n2 + 2 * n3 + C) {
+            v = expf(logs[i - n1 - n2 - 2 * n3] * logscale);
+        } else { // W1r[w][tap][ci] = W1[w][ci][tap]
+            const size_t j = i - n1 - n2 - 2 * n3 - C;
+            const int CIN = C / 2, w = (int)(j / K1), q = (int)(j % K1), tap = q / CIN, ci = q % CIN;
+            v = w1[(size_t)w * K1 + ci * 9 + tap];
+        }
+        wt[i] = v;
+    }
+}
+
+// pixel of this lane
+struct Pix {
+    int p, b, r, y, x;
+    bool live;
+};
+__device__ __forceinline__ Pix pix_of(int p, int HW, int W, int NPX)
+{
+    Pix q;
+    q.p = p;
+    q.live = p < NPX;
+    const int pp = q.live ? p : 0;
+    q.b = pp / HW;
+    q.r = pp - q.b * HW;
+    q.y = q.r / W;
+    q.x = q.r - q.y * W;
+    return q;
+}
+
+// the 3x3 neighbourhood of the head channels of x around every pixel of the tile, tap-major rows of 64: patch[k][lane],
+// k = ci*9 + (dy*3+dx); zero outside the image.  All waves of the workgroup share the work.
+template <int CIN>
+__device__ __forceinline__ void stage_patch(float *patch, const float *__restrict__ x, const Pix &q, const CondShape &s, int lane,
+                                            int wv, int J)
+{
+    const int HW = s.H * s.W;
+    // (loads are unconditional, from clamped coordinates, and zeroed afterwards: a conditional load is a branch and a
+    // branch per load serialises the round trips)
+#pragma unroll 4
+    for (int k = wv; k < 9 * CIN; k += J) {
+        const int ci = k / 9, tap = k - ci * 9, dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int yy = q.y + dy, xx = q.x + dx;
+        const bool in = q.live && yy >= 0 && yy < s.H && xx >= 0 && xx < s.W;
+        const int yc = min(max(yy, 0), s.H - 1), xc = min(max(xx, 0), s.W - 1);
+        const float v = x[((size_t)q.b * s.Cx + ci) * HW + yc * s.W + xc];
+        patch[k * 64 + lane] = in ? v : 0.f;
+    }
+}
+
+// The first convolution's weights go through the stage in sub-blocks of KB = 9 CB rows (<= 54) of 16 hidden units.
+template <int CIN> struct W1Split {
+    static constexpr int CB = CIN <= 6 ? CIN : (CIN % 6 == 0 ? 6 : 4), KB = 9 * CB, NS = CIN / CB;
+    static_assert(CIN % CB == 0 && KB * 4 <= 256, "sub-blocks tile the input channels and fit the stage");
+};
+
+// a1[j] += sum_{k in sub-block} wl[k][j] patch[k0 + k]   (reads of row k + 1 ahead of the FMAs of row k; fenced like rows_fma)
+template <int KB> __device__ __forceinline__ void hidden_block(float (&a1)[HC], const float *patch, const float *wl, int k0, int lane)
+{
+    f4 wn[HC / 4];
+    float pn = patch[k0 * 64 + lane];
+#pragma unroll
+    for (int u = 0; u < HC / 4; ++u) wn[u] = ((const f4 *)wl)[u];
+#pragma unroll 2
+    for (int k = 0; k < KB; ++k) {
+        f4 w[HC / 4];
+        const float pv = pn;
+#pragma unroll
+        for (int u = 0; u < HC / 4; ++u) w[u] = wn[u];
+        const int kn = k + 1 < KB ? k + 1 : k; // (the last iteration re-reads its own row)
+        pn = patch[(k0 + kn) * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < HC / 4; ++u) wn[u] = ((const f4 *)(wl + kn * HC))[u];
+#pragma unroll
+        for (int u = 0; u < HC / 4; ++u) {
+            a1[4 * u + 0] = fmaf(w[u][0], pv, a1[4 * u + 0]);
+            a1[4 * u + 1] = fmaf(w[u][1], pv, a1[4 * u + 1]);
+            a1[4 * u + 2] = fmaf(w[u][2], pv, a1[4 * u + 2]);
+            a1[4 * u + 3] = fmaf(w[u][3], pv, a1[4 * u + 3]);
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// acc[c] += sum_j rows[j][c] v[j]  for a staged block of NJ rows of RL floats (broadcast reads), in segments of up to 16
+// floats, the next segment's reads issued ahead of this segment's FMAs.  Unrolled (v and acc are registers) but fenced
+// segment by segment: left alone, every ds_read of the block is hoisted to the top and hundreds of registers spill.
+template <int RL, int NJ> __device__ __forceinline__ void rows_fma(float (&acc)[RL], const float *wl, const float (&v)[NJ])
+{
+    constexpr int SQ = RL <= 16 ? RL / 4 : (RL % 16 == 0 ? 4 : 3), NSEG = RL / (4 * SQ); // quads per segment, segments per row
+    static_assert(RL % (4 * SQ) == 0, "rows are whole segments");
+    f4 wn[SQ];
+#pragma unroll
+    for (int u = 0; u < SQ; ++u) wn[u] = ((const f4 *)wl)[u];
+#pragma unroll
+    for (int i = 0; i < NJ * NSEG; ++i) {
+        const int j = i / NSEG, sg = i % NSEG;
+        f4 w[SQ];
+#pragma unroll
+        for (int u = 0; u < SQ; ++u) w[u] = wn[u];
+        if (i + 1 < NJ * NSEG) {
+#pragma unroll
+            for (int u = 0; u < SQ; ++u) wn[u] = ((const f4 *)wl)[(i + 1) * SQ + u];
+        }
+#pragma unroll
+        for (int u = 0; u < SQ; ++u) {
+            const int c = 4 * (sg * SQ + u);
+            acc[c + 0] = fmaf(w[u][0], v[j], acc[c + 0]);
+            acc[c + 1] = fmaf(w[u][1], v[j], acc[c + 1]);
+            acc[c + 2] = fmaf(w[u][2], v[j], acc[c + 2]);
+            acc[c + 3] = fmaf(w[u][3], v[j], acc[c + 3]);
+        }
+        asm volatile("" ::: "memory"); // (later reads stay below this line)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// the same with v in LDS (vl[j][lane]) and the row loop rolled: for the long blocks (16 x C, C x 16), where the unrolled form
+// costs hundreds of registers whatever the fences say
+template <int RL> __device__ __forceinline__ void rows_fma_lds(float (&acc)[RL], const float *wl, const float *vl, int nj, int lane)
+{
+#pragma unroll 2
+    for (int j = 0; j < nj; ++j) {
+        const float vj = vl[j * 64 + lane];
+        const f4 *wr = (const f4 *)(wl + j * RL);
+#pragma unroll
+        for (int u = 0; u < RL / 4; ++u) {
+            const f4 w = wr[u];
+            acc[4 * u + 0] = fmaf(w[0], vj, acc[4 * u + 0]);
+            acc[4 * u + 1] = fmaf(w[1], vj, acc[4 * u + 1]);
+            acc[4 * u + 2] = fmaf(w[2], vj, acc[4 * u + 2]);
+            acc[4 * u + 3] = fmaf(w[3], vj, acc[4 * u + 3]);
+        }
+    }
+}
+
+// ---- forward 1: a2 = relu(W2 relu(W1 * x1)) ---------------------------------------------------------------------------
+// LDS: patch [K1][64] | stage [J][STAGE] | hidden [J][16][64]; the slots [J][C][64] of the final sum reuse it from the start.
+template <int C>
+__global__ __launch_bounds__(512) void k_cond_fwd1(const float *__restrict__ x, const float *__restrict__ wt, float *__restrict__ a2,
+                                                   CondShape s, int J)
+{
+    constexpr int CIN = C / 2, K1 = 9 * CIN, KB = W1Split<CIN>::KB, NS = W1Split<CIN>::NS;
+    extern __shared__ float lds[];
+    float *patch = lds, *red = lds;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float *wl = lds + K1 * 64 + wv * STAGE, *vl = lds + K1 * 64 + J * STAGE + wv * HC * 64;
+    const int HW = s.H * s.W, NPX = s.B * HW;
+    const Pix q = pix_of(blockIdx.x * 64 + lane, HW, s.W, NPX);
+    const float *__restrict__ w1t = wt, *__restrict__ w2t = wt + (size_t)K1 * s.Wd;
+    const int per = s.Wd / J, w0 = wv * per, nblk = (per / HC) * (NS + 1);
+    auto blk = [&](int t) {
+        const int wb = w0 + (t / (NS + 1)) * HC, sb = t % (NS + 1);
+        return sb < NS ? Blk{w1t + (size_t)sb * KB * s.Wd + wb, KB * 4, s.Wd} : Blk{w2t + (size_t)wb * C, 4 * C, 0};
+    };
+    stage_patch<CIN>(patch, x, q, s, lane, wv, J);
+    float acc[C], a1[HC];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.f;
+    for (int t = 0; t < nblk; ++t) {
+        __syncthreads();
+        blk_copy(wl, blk(t), lane);
+        __syncthreads();
+        const int sb = t % (NS + 1);
+        if (sb == 0) {
+#pragma unroll
+            for (int j = 0; j < HC; ++j) a1[j] = 0.f;
+        }
+        if (sb < NS) {
+            hidden_block<KB>(a1, patch, wl, sb * KB, lane);
+        } else {
+#pragma unroll
+            for (int j = 0; j < HC; ++j) vl[j * 64 + lane] = fmaxf(a1[j], 0.f); // (a wave reads back its own lanes' values)
+            rows_fma_lds<C>(acc, wl, vl, HC, lane);
+        }
+    }
+    if (J > 1) { // one slot per wave, summed in wave order
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < C; ++c) red[(wv * C + c) * 64 + lane] = acc[c];
+        __syncthreads();
+        if (q.live)
+            for (int c = wv; c < C; c += J) {
+                float t = 0.f;
+                for (int j = 0; j < J; ++j) t += red[(j * C + c) * 64 + lane];
+                a2[((size_t)q.b * C + c) * HW + q.r] = fmaxf(t, 0.f);
+            }
+    } else if (q.live) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) a2[((size_t)q.b * C + c) * HW + q.r] = fmaxf(acc[c], 0.f);
+    }
+}
+
+// offsets of the nine neighbours (dy, dx in -1..1, or mirrored) from clamped coordinates -- always inside the image, so that
+// the loads need no branch -- and the mask of the ones really inside
+__device__ __forceinline__ unsigned nine_offsets(int (&off)[9], const Pix &q, const CondShape &s, int sign)
+{
+    unsigned ok = 0;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = q.y + sign * (tap / 3 - 1), xx = q.x + sign * (tap % 3 - 1);
+        if (q.live && yy >= 0 && yy < s.H && xx >= 0 && xx < s.W) ok |= 1u << tap;
+        off[tap] = (min(max(yy, 0), s.H - 1) - q.y) * s.W + (min(max(xx, 0), s.W - 1) - q.x);
+    }
+    return ok;
+}
+
+// The two 3x3 convolutions over C channels (forward 2, backward 1) split their reduction channels over the JC waves of a
+// workgroup; a wave's NI channels are NI blocks of nine rows of C weights.
+template <int C> struct CSplit {
+    static constexpr int JC = C >= 8 ? 8 : 4, NI = (C + JC - 1) / JC;
+    static_assert(9 * C <= STAGE, "nine rows of C weights fit the stage");
+};
+
+// ---- forward 2: h = (W3 * a2 + b3) gain --------------------------------------------------------------------------------
+// LDS: slots [JC][C][64] | stage [JC][STAGE]
+template <int C>
+__global__ __launch_bounds__(512) void k_cond_fwd2(const float *__restrict__ a2, const float *__restrict__ wt,
+                                                   const float *__restrict__ b3, float *__restrict__ h, CondShape s)
+{
+    constexpr int K1 = 9 * (C / 2), JC = CSplit<C>::JC, NI = CSplit<C>::NI;
+    extern __shared__ float lds[];
+    float *red = lds;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float *wl = lds + JC * C * 64 + wv * STAGE;
+    const int HW = s.H * s.W, NPX = s.B * HW;
+    const Pix q = pix_of(blockIdx.x * 64 + lane, HW, s.W, NPX);
+    const float *__restrict__ w3t = wt + (size_t)K1 * s.Wd + (size_t)s.Wd * C;
+    const float *__restrict__ gain = w3t + (size_t)18 * C * C;
+    // (a wave whose channel index runs past C works on channel C-1 with zero inputs: no branches)
+    auto blk = [&](int it) { return Blk{w3t + (size_t)min(wv + it * JC, C - 1) * 9 * C, 9 * C / 4, 0}; };
+    int off[9];
+    const unsigned ok = nine_offsets(off, q, s, 1);
+    const float *__restrict__ ab = a2 + (size_t)q.b * C * HW + q.r;
+    float pv[NI][9];
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int ci = wv + it * JC, cc = min(ci, C - 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float v = ab[(ptrdiff_t)cc * HW + off[tap]];
+            pv[it][tap] = (ci < C && ((ok >> tap) & 1)) ? v : 0.f;
+        }
+    }
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        __syncthreads();
+        blk_copy(wl, blk(it), lane);
+        __syncthreads();
+        rows_fma<C, 9>(acc, wl, pv[it]);
+    }
+#pragma unroll
+    for (int co = 0; co < C; ++co) red[(wv * C + co) * 64 + lane] = acc[co];
+    __syncthreads();
+    if (q.live) {
+        const bool has_b = b3 != nullptr;
+        for (int co = wv; co < C; co += JC) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < JC; ++j) t += red[(j * C + co) * 64 + lane];
+            h[((size_t)q.b * C + co) * HW + q.r] = (t + (has_b ? b3[co] : 0.f)) * gain[co];
+        }
+    }
+}
+
+// ---- backward 1 -----------------------------------------------------------------------------------------------------------
+// g3 = dh gain;  d logs[c] = logscale sum h dh;  d b3[c] = sum g3 (per tile of 64 pixels: part[tile][2C], summed by the
+// caller);  g2 = [a2 > 0] (W3^T * g3)
+// operand matrices (16-bit, [row][NPXp], NPXp = pixels rounded up to 64, the padding written as zeros):
+//   g3t [C][NPXp], p3t [9C][NPXp] (the 3x3 neighbourhoods of a2: dW3 = g3t p3t^T), g2t [C][NPXp]
+// LDS as forward 2.
+template <int C>
+__global__ __launch_bounds__(512) void k_cond_bwd1(const float *__restrict__ dh, const float *__restrict__ h, const float *__restrict__ a2,
+                                                   const float *__restrict__ wt, bf16_t *__restrict__ g3t, bf16_t *__restrict__ p3t,
+                                                   bf16_t *__restrict__ g2t, float *__restrict__ part, CondShape s, int NPXp,
+                                                   float logscale)
+{
+    constexpr int K1 = 9 * (C / 2), JC = CSplit<C>::JC, NI = CSplit<C>::NI;
+    extern __shared__ float lds[];
+    float *red = lds;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float *wl = lds + JC * C * 64 + wv * STAGE;
+    const int HW = s.H * s.W, NPX = s.B * HW;
+    const int p = blockIdx.x * 64 + lane;
+    const Pix q = pix_of(p, HW, s.W, NPX);
+    const float *__restrict__ w3b = wt + (size_t)K1 * s.Wd + (size_t)s.Wd * C + (size_t)9 * C * C;
+    const float *__restrict__ gain = w3b + (size_t)9 * C * C;
+    auto blk = [&](int it) { return Blk{w3b + (size_t)min(wv + it * JC, C - 1) * 9 * C, 9 * C / 4, 0}; };
+    int offf[9], offb[9]; // forward taps (y+dy-1) and mirrored taps (y-dy+1)
+    const unsigned okf = nine_offsets(offf, q, s, 1), okb = nine_offsets(offb, q, s, -1);
+    const size_t base = (size_t)q.b * C * HW + q.r;
+    // this wave's channels: c = wv, wv + JC, ... (past C: channel C-1 read, zero used, nothing stored)
+    // the neighbourhoods of a2 go straight out
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int c = wv + it * JC, cc = min(c, C - 1);
+        float pa[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) pa[tap] = a2[base + (ptrdiff_t)cc * HW + offf[tap]];
+        if (c < C) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) p3t[(size_t)(c * 9 + tap) * NPXp + p] = narrow_bf16((okf >> tap) & 1 ? pa[tap] : 0.f);
+        }
+    }
+    float a0[NI], gv[NI][9];
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int c = wv + it * JC, cc = min(c, C - 1);
+        const bool on = q.live && c < C;
+        const float gn = gain[cc];
+        const float d0v = dh[base + (size_t)cc * HW], h0v = h[base + (size_t)cc * HW], a0v = a2[base + (size_t)cc * HW];
+        const float d0 = on ? d0v : 0.f, h0 = on ? h0v : 0.f;
+        a0[it] = on ? a0v : 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float v = dh[base + (ptrdiff_t)cc * HW + offb[tap]];
+            gv[it][tap] = (c < C && ((okb >> tap) & 1)) ? v * gn : 0.f;
+        }
+        const float g = d0 * gn;
+        const float sl = wave_sum(logscale * h0 * d0), sb = wave_sum(g);
+        if (c < C) {
+            g3t[(size_t)c * NPXp + p] = narrow_bf16(g);
+            if (lane == 0) {
+                part[(size_t)blockIdx.x * 2 * C + c] = sl;
+                part[(size_t)blockIdx.x * 2 * C + C + c] = sb;
+            }
+        }
+    }
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        __syncthreads();
+        blk_copy(wl, blk(it), lane);
+        __syncthreads();
+        rows_fma<C, 9>(acc, wl, gv[it]);
+    }
+#pragma unroll
+    for (int ci = 0; ci < C; ++ci) red[(wv * C + ci) * 64 + lane] = acc[ci];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int ci = wv + it * JC;
+        if (ci < C) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < JC; ++j) t += red[(j * C + ci) * 64 + lane];
+            g2t[(size_t)ci * NPXp + p] = narrow_bf16(a0[it] > 0.f ? t : 0.f);
+        }
+    }
+}
+
+// ---- backward 2 -----------------------------------------------------------------------------------------------------------
+// a1 recomputed; g1 = [a1 > 0] W2^T g2; operand matrices a1t [Wd][NPXp] (after the ReLU), g1t [Wd][NPXp], p1t [K1][NPXp]:
+// dW2 = g2t a1t^T, dW1 = g1t p1t^T.   LDS: patch [K1][64] | stage [J][STAGE] | g2 [C][64]
+template <int C>
+__global__ __launch_bounds__(512) void k_cond_bwd2(const float *__restrict__ x, const bf16_t *__restrict__ g2t, const float *__restrict__ wt,
+                                                   const float *__restrict__ w2, bf16_t *__restrict__ a1t, bf16_t *__restrict__ g1t,
+                                                   bf16_t *__restrict__ p1t, CondShape s, int J, int NPXp)
+{
+    constexpr int CIN = C / 2, K1 = 9 * CIN, KB = W1Split<CIN>::KB, NS = W1Split<CIN>::NS;
+    extern __shared__ float lds[];
+    float *patch = lds;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float *wl = lds + K1 * 64 + wv * STAGE;
+    const int HW = s.H * s.W, NPX = s.B * HW;
+    const int p = blockIdx.x * 64 + lane;
+    const Pix q = pix_of(p, HW, s.W, NPX);
+    const float *__restrict__ w1t = wt;
+    const int per = s.Wd / J, w0 = wv * per, nblk = (per / HC) * (NS + 1);
+    auto blk = [&](int t) { // NS sub-blocks of W1t, then the chunk's 16 columns of W2 [C][Wd]
+        const int wb = w0 + (t / (NS + 1)) * HC, sb = t % (NS + 1);
+        return sb < NS ? Blk{w1t + (size_t)sb * KB * s.Wd + wb, KB * 4, s.Wd} : Blk{w2 + wb, C * 4, s.Wd};
+    };
+    stage_patch<CIN>(patch, x, q, s, lane, wv, J);
+    float *g2l = lds + K1 * 64 + J * STAGE;
+    for (int c = wv; c < C; c += J) g2l[c * 64 + lane] = widen(g2t[(size_t)c * NPXp + p]);
+    float a1[HC];
+    for (int t = 0; t < nblk; ++t) {
+        __syncthreads();
+        blk_copy(wl, blk(t), lane);
+        __syncthreads();
+        if (t == 0)
+            for (int k = wv; k < K1; k += J) p1t[(size_t)k * NPXp + p] = narrow_bf16(patch[k * 64 + lane]);
+        const int wb = w0 + (t / (NS + 1)) * HC, sb = t % (NS + 1);
+        if (sb == 0) {
+#pragma unroll
+            for (int j = 0; j < HC; ++j) a1[j] = 0.f;
+        }
+        if (sb < NS) {
+            hidden_block<KB>(a1, patch, wl, sb * KB, lane);
+        } else { // wl = [c][16]: ga[j] = sum_c W2[c][wb + j] g2[c]
+            float ga[HC];
+#pragma unroll
+            for (int j = 0; j < HC; ++j) ga[j] = 0.f;
+            rows_fma_lds<HC>(ga, wl, g2l, C, lane);
+#pragma unroll
+            for (int j = 0; j < HC; ++j) {
+                a1t[(size_t)(wb + j) * NPXp + p] = narrow_bf16(fmaxf(a1[j], 0.f));
+                g1t[(size_t)(wb + j) * NPXp + p] = narrow_bf16(a1[j] > 0.f ? ga[j] : 0.f);
+            }
+        }
+    }
+}
+
+// ---- backward 3: dx[:, :C/2] += W1^T * g1 -----------------------------------------------------------------------------------
+// dx1[ci][p] = sum_{w,tap} W1[w][ci][tap] g1[w][p - (dy-1) W - (dx-1)]: the rows of g1t around the tile staged 16 hidden units
+// at a time in LDS (64 + 2W + 2 pixels each, one tile per wave), nine reads and 9 C/2 FMAs per hidden unit and lane; the
+// weights W1r [w][tap][ci] in blocks of four hidden units.
+// LDS: slots [J][CIN][64] | stage [J][STAGE] | tiles [J][HC][SCW] (16-bit)
+template <int C>
+__global__ __launch_bounds__(512) void k_cond_bwd3(const bf16_t *__restrict__ g1t, const float *__restrict__ wt, float *__restrict__ dx,
+                                                   CondShape s, int J, int NPXp)
+{
+    constexpr int CIN = C / 2, K1 = 9 * CIN, NB = CIN <= 6 ? 16 : (CIN <= 12 ? 8 : 4); // hidden units per weight block
+    static_assert(NB * K1 <= STAGE && HC % NB == 0, "a block of hidden units' weights fits the stage");
+    extern __shared__ float lds[];
+    const int SCW = 64 + 2 * s.W + 2;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float *red = lds;
+    float *wl = lds + J * CIN * 64 + wv * STAGE;
+    bf16_t *tile = (bf16_t *)(lds + J * CIN * 64 + J * STAGE) + (size_t)wv * HC * SCW;
+    const int HW = s.H * s.W, NPX = s.B * HW;
+    const Pix q = pix_of(blockIdx.x * 64 + lane, HW, s.W, NPX);
+    const float *__restrict__ w1r = wt + (size_t)K1 * s.Wd + (size_t)s.Wd * C + (size_t)18 * C * C + C;
+    unsigned okb = 0;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = q.y - (tap / 3 - 1), xx = q.x - (tap % 3 - 1);
+        if (q.live && yy >= 0 && yy < s.H && xx >= 0 && xx < s.W) okb |= 1u << tap;
+    }
+    float acc[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) acc[c] = 0.f;
+    const int first = blockIdx.x * 64 - (s.W + 1); // flattened pixel of tile entry 0
+    const int per = s.Wd / J, w0 = wv * per, nblk = per / NB;
+    auto blk = [&](int t) { return Blk{w1r + (size_t)(w0 + t * NB) * K1, NB * K1 / 4, 0}; };
+    for (int t = 0; t < nblk; ++t) {
+        const int jb = (t * NB) % HC; // position in the 16-unit tile
+        bf16_t v[HC][3];
+        if (jb == 0) { // the next 16 rows of g1t (SCW <= 3 * 64 for images up to 63 wide; wider ones take more rounds);
+                       // clamped, unconditional loads (no branch per load), zeroed at the store
+            const int wb = w0 + t * NB;
+#pragma unroll
+            for (int j = 0; j < HC; ++j)
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) {
+                    const int pp = min(max(first + lane + 64 * rr, 0), NPXp - 1);
+                    v[j][rr] = g1t[(size_t)(wb + j) * NPXp + pp];
+                }
+        }
+        __syncthreads();
+        blk_copy(wl, blk(t), lane);
+        if (jb == 0) {
+            const int wb = w0 + t * NB;
+#pragma unroll
+            for (int j = 0; j < HC; ++j)
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) {
+                    const int e = lane + 64 * rr, pp = first + e;
+                    if (e < SCW) tile[j * SCW + e] = (pp >= 0 && pp < NPXp) ? v[j][rr] : (bf16_t)0;
+                }
+            for (int e = lane + 192; e < SCW; e += 64) // images wider than 63 pixels
+                for (int j = 0; j < HC; ++j) {
+                    const int pp = first + e;
+                    tile[j * SCW + e] = (pp >= 0 && pp < NPXp) ? g1t[(size_t)(wb + j) * NPXp + pp] : (bf16_t)0;
+                }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int j = 0; j < NB; ++j) {
+            float gvv[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+                gvv[tap] = (okb >> tap) & 1 ? widen(tile[(jb + j) * SCW + lane + (2 - tap / 3) * s.W + (2 - tap % 3)]) : 0.f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float *wr = wl + (j * 9 + tap) * CIN;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) acc[ci] = fmaf(wr[ci], gvv[tap], acc[ci]);
+            }
+        }
+    }
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) red[(wv * CIN + ci) * 64 + lane] = acc[ci];
+    __syncthreads();
+    if (q.live)
+        for (int ci = wv; ci < CIN; ci += J) {
+            float t = 0.f;
+            for (int j = 0; j < J; ++j) t += red[(j * CIN + ci) * 64 + lane];
+            dx[((size_t)q.b * s.Cx + ci) * HW + q.r] += t;
+        }
+}
+
+// hidden units are split over J waves: as many as divide them into whole chunks, up to 8 (work per wave is small and latency
+// bound: more waves, shorter chains)
+static int pick_j(int Wd)
+{
+    int J = 1;
+    while (J < 8 && Wd % (2 * J * HC) == 0) J *= 2;
+    return J;
+}
+
+template <int C> struct CondLaunch {
+    static constexpr int K1 = 9 * (C / 2);
+    static int forward(const float *x, const float *wt, const float *b3, float *a2, float *h, CondShape s, hipStream_t st)
+    {
+        static LdsOptIn opt;
+        static LdsOptIn opt2;
+        const int NPX = s.B * s.H * s.W, tiles = (NPX + 63) / 64, J = pick_j(s.Wd);
+        const int a_ = K1 * 64 + J * STAGE + J * HC * 64, b_ = J > 1 ? J * C * 64 : 0;
+        const int lds = (a_ > b_ ? a_ : b_) * (int)sizeof(float);
+        constexpr int JC = CSplit<C>::JC, ldsc = (JC * C * 64 + JC * STAGE) * (int)sizeof(float);
+        if (int rc = lds_opt_in(opt, (const void *)k_cond_fwd1<C>, 160 * 1024 - 256)) return rc;
+        if (int rc = lds_opt_in(opt2, (const void *)k_cond_fwd2<C>, 160 * 1024 - 256)) return rc;
+        hipLaunchKernelGGL(k_cond_fwd1<C>, dim3(tiles), dim3(64 * J), lds, st, x, wt, a2, s, J);
+        hipLaunchKernelGGL(k_cond_fwd2<C>, dim3(tiles), dim3(64 * JC), ldsc, st, (const float *)a2, wt, b3, h, s);
+        IFL_HIP(hipGetLastError());
+        return IFL_OK;
+    }
+    static int backward(const float *x, const float *dh, const float *h, const float *a2, const float *wt, const float *w2,
+                        bf16_t *g3t, bf16_t *p3t, bf16_t *g2t, bf16_t *a1t, bf16_t *g1t, bf16_t *p1t, float *part, float *dx,
+                        CondShape s, float logscale, hipStream_t st)
+    {
+        static LdsOptIn opt;
+        static LdsOptIn opt1;
+        const int NPX = s.B * s.H * s.W, tiles = (NPX + 63) / 64, J = pick_j(s.Wd), NPXp = tiles * 64;
+        constexpr int JC = CSplit<C>::JC, ldsc = (JC * C * 64 + JC * STAGE) * (int)sizeof(float);
+        if (int rc = lds_opt_in(opt1, (const void *)k_cond_bwd1<C>, 160 * 1024 - 256)) return rc;
+        const int lds2 = (K1 * 64 + J * STAGE + C * 64) * (int)sizeof(float);
+        const int lds3 = (J * (C / 2) * 64 + J * STAGE) * (int)sizeof(float) + J * HC * (64 + 2 * s.W + 2) * (int)sizeof(bf16_t);
+        static LdsOptIn opt3;
+        if (lds3 > 160 * 1024 - 256) IFL_FAIL(IFL_EUNSUPPORTED, "ifl_cond_backward_f32: images of width %d are too wide", s.W);
+        if (int rc = lds_opt_in(opt, (const void *)k_cond_bwd2<C>, 160 * 1024 - 256)) return rc;
+        if (int rc = lds_opt_in(opt3, (const void *)k_cond_bwd3<C>, 160 * 1024 - 256)) return rc;
+        hipLaunchKernelGGL(k_cond_bwd1<C>, dim3(tiles), dim3(64 * JC), ldsc, st, dh, h, a2, wt, g3t, p3t, g2t, part, s, NPXp, logscale);
+        hipLaunchKernelGGL(k_cond_bwd2<C>, dim3(tiles), dim3(64 * J), lds2, st, x, (const bf16_t *)g2t, wt, w2, a1t, g1t, p1t, s, J,
+                           NPXp);
+        hipLaunchKernelGGL(k_cond_bwd3<C>, dim3(tiles), dim3(64 * J), lds3, st, (const bf16_t *)g1t, wt, dx, s, J, NPXp);
+        IFL_HIP(hipGetLastError());
+        return IFL_OK;
+    }
+};
+
+static bool cond_c_ok(int C) { return C == 4 || C == 8 || C == 12 || C == 16 || C == 24 || C == 32 || C == 48; }
+
+static int cond_check(const char *who, int B, int C, int H, int W, int Wd, int Cx)
+{
+    if (B < 0 || H < 1 || W < 1) IFL_FAIL(IFL_EINVAL, "%s: bad shape B=%d H=%d W=%d", who, B, H, W);
+    if (!cond_c_ok(C)) IFL_FAIL(IFL_EUNSUPPORTED, "%s: C=%d is not one of 4, 8, 12, 16, 24, 32, 48", who, C);
+    if (Wd < HC || Wd % HC) IFL_FAIL(IFL_EUNSUPPORTED, "%s: width %d must be a multiple of %d", who, Wd, HC);
+    if (Cx < C / 2) IFL_FAIL(IFL_EINVAL, "%s: the input has %d channels, the conditioner reads %d", who, Cx, C / 2);
+    if ((size_t)B * H * W > (size_t)1 << 30 || W > 4096) IFL_FAIL(IFL_EUNSUPPORTED, "%s: too many pixels", who);
+    return IFL_OK;
+}
+
+#define IFL_COND_DISPATCH(C, CALL)      \
+    switch (C) {                        \
+    case 4: return CondLaunch<4>::CALL; \
+    case 8: return CondLaunch<8>::CALL; \
+    case 12: return CondLaunch<12>::CALL; \
+    case 16: return CondLaunch<16>::CALL; \
+    case 24: return CondLaunch<24>::CALL; \
+    case 32: return CondLaunch<32>::CALL; \
+    default: return CondLaunch<48>::CALL; \
+    }
+
+} // namespace ifl
+
+using namespace ifl;
+
+extern "C" {
+
+int ifl_cond_supported(int C, int width) { return cond_c_ok(C) && width >= HC && width % HC == 0; }
+
+size_t ifl_cond_weights_floats(int C, int width) { return cond_wt_floats(C, width); }
+
+int ifl_cond_pixels_padded(int B, int H, int W) { return (int)(((size_t)B * H * W + 63) / 64 * 64); }
+
+int ifl_cond_prep_f32(const float *w1, const float *w2, const float *w3, const float *logs, float *wt, int C, int width,
+                      float logscale_factor, ifl_stream_t stream)
+{
+    clear_error();
+    if (int rc = cond_check("ifl_cond_prep_f32", 0, C, 1, 1, width, C)) return rc;
+    if (!w1 || !w2 || !w3 || !logs || !wt) IFL_FAIL(IFL_EINVAL, "ifl_cond_prep_f32: null pointer");
+    const size_t n = cond_wt_floats(C, width);
+    hipLaunchKernelGGL(k_cond_prep, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0,
+                       (hipStream_t)stream, w1, w2, w3, logs, wt, C, width, logscale_factor);
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+
+int ifl_cond_forward_f32(const float *x, int x_channels, const float *wt, const float *b3, float *a2, float *h, int B, int C, int H,
+                         int W, int width, ifl_stream_t stream)
+{
+    clear_error();
+    if (int rc = cond_check("ifl_cond_forward_f32", B, C, H, W, width, x_channels)) return rc;
+    if (B == 0) return IFL_OK;
+    if (!x || !wt || !a2 || !h) IFL_FAIL(IFL_EINVAL, "ifl_cond_forward_f32: null pointer");
+    const CondShape s{B, H, W, width, x_channels};
+    IFL_COND_DISPATCH(C, forward(x, wt, b3, a2, h, s, (hipStream_t)stream));
+}
+
+int ifl_cond_backward_f32(const float *x, int x_channels, const float *dh, const float *h, const float *a2, const float *wt,
+                          const float *w2, uint16_t *g3t, uint16_t *p3t, uint16_t *g2t, uint16_t *a1t, uint16_t *g1t, uint16_t *p1t,
+                          float *part, float *dx, int B, int C, int H, int W, int width, float logscale_factor,
+                          ifl_stream_t stream)
+{
+    clear_error();
+    if (int rc = cond_check("ifl_cond_backward_f32", B, C, H, W, width, x_channels)) return rc;
+    if (B == 0) return IFL_OK;
+    if (!x || !dh || !h || !a2 || !wt || !w2 || !g3t || !p3t || !g2t || !a1t || !g1t || !p1t || !part || !dx)
+        IFL_FAIL(IFL_EINVAL, "ifl_cond_backward_f32: null pointer");
+    const CondShape s{B, H, W, width, x_channels};
+    IFL_COND_DISPATCH(C, backward(x, dh, h, a2, wt, w2, g3t, p3t, g2t, a1t, g1t, p1t, part, dx, s, logscale_factor,
+                                  (hipStream_t)stream));
+}
+
+} // extern "C"

@@ -65,11 +65,38 @@ class _Affine(torch.autograd.Function):
         return H.coupling_backward(gy.contiguous(), gld.contiguous() if gld is not None else None, x, h)
 
 
+class _CondAffine(torch.autograd.Function):
+    """(x, the conditioner's parameters) -> (y, sum log_s): conditioner and affine map on the library, forward and backward
+    (csrc/conditioner.hip: two launches for h = net(x1), three + three GEMMs for its backward, next to the affine map's
+    one each way).  fp32 throughout -- under autocast too: the net's arithmetic is small, its launch count is not."""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, x, w1, w2, w3, b3, logs, logscale):
+        x = x.contiguous()
+        wt = H.cond_prep(w1.contiguous(), w2.contiguous(), w3.contiguous(), logs.contiguous(), logscale)
+        a2, h = H.cond_forward(x, wt, b3, w3.shape[0], w1.shape[0])
+        ctx.save_for_backward(x, h, a2, wt, w2)
+        ctx.logscale, ctx.has_bias = logscale, b3 is not None
+        return H.coupling(x, h)
+
+    @staticmethod
+    @_bwd32
+    def backward(ctx, gy, gld):
+        x, h, a2, wt, w2 = ctx.saved_tensors
+        gx, gh = H.coupling_backward(gy.contiguous(), gld.contiguous() if gld is not None else None, x, h)
+        dw1, dw2, dw3, dlogs, db3 = H.cond_backward(x, gh, h, a2, wt, w2.contiguous(), gx, w2.shape[1], ctx.logscale)
+        return gx, dw1, dw2, dw3, (db3 if ctx.has_bias else None), dlogs, None
+
+
 def _on_library(x):
     return x.dim() == 4 and x.is_cuda and x.size(1) % 2 == 0 and x.dtype in (torch.float32, torch.float16, torch.bfloat16)
 
 
 class Coupling(FlowLayer):
+    channels_last = True  # the conditioner's 16-bit convolutions on NHWC operands (_net_channels_last)
+    fused = True  # conditioner + affine map on csrc/conditioner.hip where its shapes are covered (_CondAffine)
+
     def __init__(self, input_size, width=512, n_context=None):
         super().__init__()
         channels = input_size[0]
@@ -81,12 +108,25 @@ class Coupling(FlowLayer):
             nn.Conv2d(width, channels, (1, 1), bias=False), nn.ReLU(),
             Conv2dZero(channels, channels))
 
+    def _fusable(self, x, context):
+        c1, c2, c3 = self.net[0], self.net[2], self.net[4]
+        return (self.fused and context is None and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32
+                and self.n_channels % 2 == 0 and H.cond_supported(self.n_channels, self.width)
+                and c3.stride == (1, 1) and c3.padding == (1, 1) and c3.dilation == (1, 1) and c3.groups == 1
+                and c3.kernel_size == (3, 3) and c1.weight.dtype == torch.float32)
+
+    def _fused_h(self, x):
+        c1, c2, c3 = self.net[0], self.net[2], self.net[4]
+        wt = H.cond_prep(c1.weight.detach().contiguous(), c2.weight.detach().contiguous(), c3.weight.detach().contiguous(),
+                         c3.logs.detach().contiguous(), c3.logscale_factor)
+        return H.cond_forward(x, wt, None if c3.bias is None else c3.bias.detach(), self.n_channels, self.width)[1]
+
     def _conditioner(self, x, context):
         assert (context is not None) == self.uses_context
         x1 = x[:, :self.half_channels]
         if context is not None:
             x1 = torch.cat([x1, context], dim=1)
-        if x1.is_cuda and x1.dim() == 4 and torch.is_autocast_enabled("cuda"):
+        if self.channels_last and x1.is_cuda and x1.dim() == 4 and torch.is_autocast_enabled("cuda"):
             return self._net_channels_last(x1, torch.get_autocast_dtype("cuda"))
         return self.net(x1)
 
@@ -111,12 +151,18 @@ class Coupling(FlowLayer):
         return x1, x2, LOGS_RANGE * torch.tanh(h[:, 0::2] / LOGS_RANGE), h[:, 1::2]
 
     def forward(self, input, context=None):
+        if self._fusable(input, context):
+            c1, c2, c3 = self.net[0], self.net[2], self.net[4]
+            return _CondAffine.apply(input, c1.weight, c2.weight, c3.weight, c3.bias, c3.logs, c3.logscale_factor)
         if _on_library(input):
             return _Affine.apply(input, self._conditioner(input, context))
         x1, x2, log_s, t = self.get_xs_logs_t(input, context)
         return torch.cat([x1, torch.addcmul(t, x2, log_s.exp())], dim=1), log_s.sum(dim=(1, 2, 3))
 
     def reverse(self, input, context=None):
+        if not torch.is_grad_enabled() and self._fusable(input, context):
+            x = input.contiguous()
+            return H.coupling(x, self._fused_h(x), reverse=True)
         if _on_library(input) and input.dtype in (torch.float32, torch.bfloat16) and not torch.is_grad_enabled():
             return H.coupling(input.contiguous(), self._conditioner(input, context).to(input.dtype).contiguous(), reverse=True)
         x1, y2, log_s, t = self.get_xs_logs_t(input, context)

@@ -59,6 +59,13 @@ SIGNATURES = {
     "ifl_actnorm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ifl_actnorm_backward_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ifl_squeeze_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ifl_cond_supported": (_i, [_i, _i]),
+    "ifl_cond_weights_floats": (_sz, [_i, _i]),
+    "ifl_cond_pixels_padded": (_i, [_i, _i, _i]),
+    "ifl_cond_prep_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "ifl_cond_forward_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ifl_cond_backward_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
+                                   _f, _vp]),
     "ifl_coupling_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ifl_coupling_backward_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ifl_activation_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -594,6 +601,72 @@ def coupling_backward(gy, g_logdet, x, h):
                                              _stream())
     _check(rc, "ifl_coupling_backward_" + sfx)
     return gx, gh
+
+
+# ---- the coupling's conditioner (csrc/conditioner.hip) -----------------------------------------------------------------
+def cond_supported(C, width):
+    """shapes the fused conditioner covers (others stay on the layer's convolutions)"""
+    return bool(lib().ifl_cond_supported(int(C), int(width)))
+
+
+def cond_prep(w1, w2, w3, logs, logscale_factor):
+    """transposed copies of the three kernels + the gain exp(logscale_factor logs): once per weight update"""
+    for t, n in ((w1, "w1"), (w2, "w2"), (w3, "w3"), (logs, "logs")):
+        _chk_tensor(t, n)
+    width, C = w1.shape[0], w3.shape[0]
+    if tuple(w1.shape) != (width, C // 2, 3, 3) or tuple(w2.shape[:2]) != (C, width) or w2.numel() != C * width or \
+            tuple(w3.shape) != (C, C, 3, 3) or logs.numel() != C:
+        raise RuntimeError("conditioner kernels must be (width, C/2, 3, 3), (C, width, 1, 1), (C, C, 3, 3)")
+    dev = _same_device(w1, w2, w3, logs)
+    wt = torch.empty(lib().ifl_cond_weights_floats(C, width), dtype=torch.float32, device=dev)
+    with _on(dev):
+        rc = lib().ifl_cond_prep_f32(_ptr(w1), _ptr(w2), _ptr(w3), _ptr(logs), _ptr(wt), C, width, float(logscale_factor), _stream())
+    _check(rc, "ifl_cond_prep_f32")
+    return wt
+
+
+def cond_forward(x, wt, b3, C, width):
+    """(a2, h): h = Coupling.net(x[:, :C/2]) (inf/layers/coupling.py:47-62), a2 = the second ReLU's output (for the backward)"""
+    B, Cx, H, W = _chk4(x, "input")
+    _chk_tensor(wt, "weights")
+    if b3 is not None:
+        _chk_tensor(b3, "bias")
+    dev = _same_device(x, wt, b3)
+    a2 = torch.empty(B, C, H, W, dtype=torch.float32, device=dev)
+    h = torch.empty(B, C, H, W, dtype=torch.float32, device=dev)
+    with _on(dev):
+        rc = lib().ifl_cond_forward_f32(_ptr(x), Cx, _ptr(wt), _ptr(b3), _ptr(a2), _ptr(h), B, C, H, W, width, _stream())
+    _check(rc, "ifl_cond_forward_f32")
+    return a2, h
+
+
+def cond_backward(x, dh, h, a2, wt, w2, dx, width, logscale_factor):
+    """dx[:, :C/2] += the input gradient (in place); returns (dW1, dW2, dW3, d logs, d b3) -- the three kernels' gradients
+    through library GEMMs on the operand matrices the kernels write (include/invflow.h)."""
+    B, Cx, H, W = _chk4(x, "input")
+    C = h.shape[1]
+    for t, n in ((dh, "grad_h"), (h, "h"), (a2, "a2"), (wt, "weights"), (w2, "w2"), (dx, "grad_input")):
+        _chk_tensor(t, n)
+    if dh.shape != h.shape or a2.shape != h.shape or dx.shape != x.shape:
+        raise RuntimeError("conditioner backward: shapes do not match the forward's")
+    dev = _same_device(x, dh, h, a2, wt, w2, dx)
+    P = lib().ifl_cond_pixels_padded(B, H, W)
+    K1 = 9 * (C // 2)
+    bf = torch.bfloat16
+    ops = torch.empty((2 * C + 9 * C + 2 * width + K1) * P, dtype=bf, device=dev)  # one allocation, six matrices
+    g3t, p3t, g2t, a1t, g1t, p1t = (m.view(-1, P) for m in ops.split([C * P, 9 * C * P, C * P, width * P, width * P, K1 * P]))
+    part = torch.empty(P // 64, 2 * C, dtype=torch.float32, device=dev)
+    with _on(dev):
+        rc = lib().ifl_cond_backward_f32(_ptr(x), Cx, _ptr(dh), _ptr(h), _ptr(a2), _ptr(wt), _ptr(w2), _ptr(g3t), _ptr(p3t), _ptr(g2t),
+                                         _ptr(a1t), _ptr(g1t), _ptr(p1t), _ptr(part), _ptr(dx), B, C, H, W, width,
+                                         float(logscale_factor), _stream())
+    _check(rc, "ifl_cond_backward_f32")
+    f32 = torch.float32
+    dw1 = torch.mm(g1t, p1t.t(), out_dtype=f32).view(width, C // 2, 3, 3)
+    dw2 = torch.mm(g2t, a1t.t(), out_dtype=f32).view(C, width, 1, 1)
+    dw3 = torch.mm(g3t, p3t.t(), out_dtype=f32).view(C, C, 3, 3)
+    sums = part.sum(0)
+    return dw1, dw2, dw3, sums[:C], sums[C:]
 
 
 # ---- activations of the Glow step (csrc/glow_step.hip) --------------------------------------------------------------

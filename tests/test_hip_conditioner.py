@@ -1,0 +1,87 @@
+"""GPU: the fused conditioner of the affine coupling (csrc/conditioner.hip, ifl_cond_*) against the layer's own module tree --
+the reference's `Coupling.net` (inf/layers/coupling.py:47-62: 3x3 conv, ReLU, 1x1 conv, ReLU, Conv2dZero) on library
+convolutions in fp32.  Forward: fp32 FMA both ways, tolerance 2e-5 of the output's scale.  Backward: the weight gradients and
+the input gradient go through 16-bit operand matrices (bf16, fp32 accumulate -- the precision of the bf16 autocast step
+these models train in): 2e-2 of each gradient's largest entry; d logs / d bias are fp32 sums: 1e-4."""
+import pytest
+import torch
+
+import conftest  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _coupling(C, width, seed):
+    from inf.layers.coupling import Coupling
+    torch.manual_seed(seed)
+    layer = Coupling((C, 1, 1), width=width).cuda()
+    c3 = layer.net[4]
+    with torch.no_grad():  # (zero-initialised in the reference: give every parameter a value)
+        c3.weight.normal_(0, 0.05)
+        c3.bias = torch.nn.Parameter(torch.randn(C, device="cuda") * 0.1)
+        c3.logs = torch.nn.Parameter(torch.randn(C, device="cuda") * 0.1)
+    return layer
+
+
+def _run(layer, x, gy, gld, fused):
+    from inf.layers.coupling import Coupling
+    Coupling.fused = fused
+    try:
+        for p in layer.parameters():
+            p.grad = None
+        xin = x.clone().requires_grad_()
+        y, ld = layer(xin)
+        (y * gy).sum().add((ld * gld).sum()).backward()
+        c1, c2, c3 = layer.net[0], layer.net[2], layer.net[4]
+        return y.detach(), ld.detach(), xin.grad, [p.grad.clone() for p in (c1.weight, c2.weight, c3.weight, c3.bias, c3.logs)]
+    finally:
+        Coupling.fused = True
+
+
+SHAPES = [(100, 4, 14, 14, 512), (100, 8, 7, 7, 512), (32, 12, 16, 16, 128), (32, 24, 8, 8, 128), (13, 12, 16, 16, 256),
+          (13, 24, 8, 8, 256), (13, 48, 4, 4, 256), (3, 16, 5, 3, 32), (1, 32, 2, 2, 16), (2, 4, 1, 9, 64), (5, 8, 16, 16, 48)]
+
+
+@pytest.mark.parametrize("B,C,H,W,width", SHAPES)
+def test_fused_conditioner_matches_the_module_tree(B, C, H, W, width):
+    import invflow_hip as Hh
+    assert Hh.cond_supported(C, width)
+    layer = _coupling(C, width, seed=B + C)
+    torch.manual_seed(7)
+    x = torch.randn(B, C, H, W, device="cuda")
+    gy, gld = torch.randn(B, C, H, W, device="cuda"), torch.randn(B, device="cuda")
+    y1, ld1, gx1, gp1 = _run(layer, x, gy, gld, fused=True)
+    y0, ld0, gx0, gp0 = _run(layer, x, gy, gld, fused=False)
+    assert torch.allclose(y1, y0, rtol=0, atol=2e-5 * max(1.0, float(y0.abs().max())))
+    assert torch.allclose(ld1, ld0, rtol=0, atol=2e-5 * max(1.0, float(ld0.abs().max())))
+    assert float((gx1 - gx0).abs().max()) <= 2e-2 * float(gx0.abs().max())
+    for name, a, b, tol in zip(("dW1", "dW2", "dW3", "db3", "dlogs"), gp1, gp0, (2e-2, 2e-2, 2e-2, 1e-4, 1e-4)):
+        assert a.shape == b.shape, name
+        assert float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-6), name
+    # reverse of forward (sampling direction), no grad
+    with torch.no_grad():
+        assert torch.allclose(layer.reverse(y1), x, atol=1e-4 * max(1.0, float(x.abs().max())))
+
+
+def test_fused_conditioner_is_reproducible_bit_for_bit():
+    """no float atomics: two runs of forward + backward give identical bits (GEMMs included)"""
+    layer = _coupling(12, 128, seed=3)
+    x = torch.randn(32, 12, 16, 16, device="cuda")
+    gy, gld = torch.randn_like(x), torch.randn(32, device="cuda")
+    a = _run(layer, x, gy, gld, fused=True)
+    b = _run(layer, x, gy, gld, fused=True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert all(torch.equal(p, q) for p, q in zip(a[3], b[3]))
+
+
+def test_unsupported_shapes_keep_the_convolutions_and_bad_calls_fail_loudly():
+    import invflow_hip as Hh
+    from inf.layers.coupling import Coupling
+    assert not Hh.cond_supported(6, 128) and not Hh.cond_supported(12, 100)
+    layer = Coupling((6, 1, 1), width=64).cuda()
+    x = torch.randn(2, 6, 4, 4, device="cuda")
+    assert not layer._fusable(x, None)
+    y, ld = layer(x)  # zero-initialised last convolution: the identity
+    assert torch.allclose(y, x) and float(ld.abs().max()) == 0.0
+    with pytest.raises(RuntimeError, match="not one of"):
+        Hh.cond_forward(x, torch.zeros(8, device="cuda"), None, 6, 64)

@@ -268,7 +268,9 @@ int ifl_coupling_backward_bf16(const uint16_t *gy, const float *g_logdet, const 
  *   dx[:, :C/2] += the input gradient (dx: [B][x_channels][H][W], already holding the coupling's direct part);
  *   part [tiles][2C], tiles = P/64, P = ifl_cond_pixels_padded(B,H,W): per-tile sums -- column sums give d logs (first C)
  *     and d b3 (last C);
- *   the operands of the weight gradients as bf16 matrices with P columns (pixel-major, zero in the padding):
+ *   the operands of the weight gradients as matrices with P columns (pixel-major, zero in the padding), bf16 (operands_f32
+ *   = 0: the precision of a bf16 autocast step) or fp32 (operands_f32 = 1: an fp32 step keeps fp32-accurate gradients; the
+ *   input gradient goes through g1t and follows the same choice):
  *     g3t [C][P], p3t [9C][P]:    dW3 [C][C*9]       = g3t p3t^T
  *     g2t [C][P], a1t [width][P]: dW2 [C][width]     = g2t a1t^T
  *     g1t [width][P], p1t [9C/2][P]: dW1 [width][C/2*9] = g1t p1t^T
@@ -282,7 +284,7 @@ int ifl_cond_prep_f32(const float *w1, const float *w2, const float *w3, const f
 int ifl_cond_forward_f32(const float *x, int x_channels, const float *wt, const float *b3, float *a2, float *h, int B, int C, int H,
                          int W, int width, ifl_stream_t stream);
 int ifl_cond_backward_f32(const float *x, int x_channels, const float *dh, const float *h, const float *a2, const float *wt,
-                          const float *w2, uint16_t *g3t, uint16_t *p3t, uint16_t *g2t, uint16_t *a1t, uint16_t *g1t, uint16_t *p1t,
+                          const float *w2, void *g3t, void *p3t, void *g2t, void *a1t, void *g1t, void *p1t, int operands_f32,
                           float *part, float *dx, int B, int C, int H, int W, int width, float logscale_factor,
                           ifl_stream_t stream);
 

@@ -47,6 +47,10 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// operand matrices of the weight-gradient GEMMs: bf16 (the autocast step) or fp32 (an fp32 step keeps fp32 gradients)
+__device__ __forceinline__ void put_op(bf16_t *p, float v) { *p = narrow_bf16(v); }
+__device__ __forceinline__ void put_op(float *p, float v) { *p = v; }
+
 // A block of weights: nq 16-byte quads, either contiguous or rows of four quads (16 floats) `stride` floats apart.
 struct Blk {
     const float *g;
@@ -370,10 +374,10 @@ __global__ __launch_bounds__(512) void k_cond_fwd2(const float *__restrict__ a2,
 // operand matrices (16-bit, [row][NPXp], NPXp = pixels rounded up to 64, the padding written as zeros):
 //   g3t [C][NPXp], p3t [9C][NPXp] (the 3x3 neighbourhoods of a2: dW3 = g3t p3t^T), g2t [C][NPXp]
 // LDS as forward 2.
-template <int C>
+template <int C, class T>
 __global__ __launch_bounds__(512) void k_cond_bwd1(const float *__restrict__ dh, const float *__restrict__ h, const float *__restrict__ a2,
-                                                   const float *__restrict__ wt, bf16_t *__restrict__ g3t, bf16_t *__restrict__ p3t,
-                                                   bf16_t *__restrict__ g2t, float *__restrict__ part, CondShape s, int NPXp,
+                                                   const float *__restrict__ wt, T *__restrict__ g3t, T *__restrict__ p3t,
+                                                   T *__restrict__ g2t, float *__restrict__ part, CondShape s, int NPXp,
                                                    float logscale)
 {
     constexpr int K1 = 9 * (C / 2), JC = CSplit<C>::JC, NI = CSplit<C>::NI;
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(512) void k_cond_bwd1(const float *__restrict__ dh,
         for (int tap = 0; tap < 9; ++tap) pa[tap] = a2[base + (ptrdiff_t)cc * HW + offf[tap]];
         if (c < C) {
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) p3t[(size_t)(c * 9 + tap) * NPXp + p] = narrow_bf16((okf >> tap) & 1 ? pa[tap] : 0.f);
+            for (int tap = 0; tap < 9; ++tap) put_op(p3t + (size_t)(c * 9 + tap) * NPXp + p, (okf >> tap) & 1 ? pa[tap] : 0.f);
         }
     }
     float a0[NI], gv[NI][9];
@@ -420,7 +424,7 @@ __global__ __launch_bounds__(512) void k_cond_bwd1(const float *__restrict__ dh,
         const float g = d0 * gn;
         const float sl = wave_sum(logscale * h0 * d0), sb = wave_sum(g);
         if (c < C) {
-            g3t[(size_t)c * NPXp + p] = narrow_bf16(g);
+            put_op(g3t + (size_t)c * NPXp + p, g);
             if (lane == 0) {
                 part[(size_t)blockIdx.x * 2 * C + c] = sl;
                 part[(size_t)blockIdx.x * 2 * C + C + c] = sb;
@@ -447,7 +451,7 @@ __global__ __launch_bounds__(512) void k_cond_bwd1(const float *__restrict__ dh,
             float t = 0.f;
 #pragma unroll
             for (int j = 0; j < JC; ++j) t += red[(j * C + ci) * 64 + lane];
-            g2t[(size_t)ci * NPXp + p] = narrow_bf16(a0[it] > 0.f ? t : 0.f);
+            put_op(g2t + (size_t)ci * NPXp + p, a0[it] > 0.f ? t : 0.f);
         }
     }
 }
@@ -455,10 +459,10 @@ __global__ __launch_bounds__(512) void k_cond_bwd1(const float *__restrict__ dh,
 // ---- backward 2 -----------------------------------------------------------------------------------------------------------
 // a1 recomputed; g1 = [a1 > 0] W2^T g2; operand matrices a1t [Wd][NPXp] (after the ReLU), g1t [Wd][NPXp], p1t [K1][NPXp]:
 // dW2 = g2t a1t^T, dW1 = g1t p1t^T.   LDS: patch [K1][64] | stage [J][STAGE] | g2 [C][64]
-template <int C>
-__global__ __launch_bounds__(512) void k_cond_bwd2(const float *__restrict__ x, const bf16_t *__restrict__ g2t, const float *__restrict__ wt,
-                                                   const float *__restrict__ w2, bf16_t *__restrict__ a1t, bf16_t *__restrict__ g1t,
-                                                   bf16_t *__restrict__ p1t, CondShape s, int J, int NPXp)
+template <int C, class T>
+__global__ __launch_bounds__(512) void k_cond_bwd2(const float *__restrict__ x, const T *__restrict__ g2t, const float *__restrict__ wt,
+                                                   const float *__restrict__ w2, T *__restrict__ a1t, T *__restrict__ g1t,
+                                                   T *__restrict__ p1t, CondShape s, int J, int NPXp)
 {
     constexpr int CIN = C / 2, K1 = 9 * CIN, KB = W1Split<CIN>::KB, NS = W1Split<CIN>::NS;
     extern __shared__ float lds[];
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(512) void k_cond_bwd2(const float *__restrict__ x, 
         blk_copy(wl, blk(t), lane);
         __syncthreads();
         if (t == 0)
-            for (int k = wv; k < K1; k += J) p1t[(size_t)k * NPXp + p] = narrow_bf16(patch[k * 64 + lane]);
+            for (int k = wv; k < K1; k += J) put_op(p1t + (size_t)k * NPXp + p, patch[k * 64 + lane]);
         const int wb = w0 + (t / (NS + 1)) * HC, sb = t % (NS + 1);
         if (sb == 0) {
 #pragma unroll
@@ -498,8 +502,8 @@ __global__ __launch_bounds__(512) void k_cond_bwd2(const float *__restrict__ x, 
             rows_fma_lds<HC>(ga, wl, g2l, C, lane);
 #pragma unroll
             for (int j = 0; j < HC; ++j) {
-                a1t[(size_t)(wb + j) * NPXp + p] = narrow_bf16(fmaxf(a1[j], 0.f));
-                g1t[(size_t)(wb + j) * NPXp + p] = narrow_bf16(a1[j] > 0.f ? ga[j] : 0.f);
+                put_op(a1t + (size_t)(wb + j) * NPXp + p, fmaxf(a1[j], 0.f));
+                put_op(g1t + (size_t)(wb + j) * NPXp + p, a1[j] > 0.f ? ga[j] : 0.f);
             }
         }
     }
@@ -510,8 +514,8 @@ __global__ __launch_bounds__(512) void k_cond_bwd2(const float *__restrict__ x, 
 // at a time in LDS (64 + 2W + 2 pixels each, one tile per wave), nine reads and 9 C/2 FMAs per hidden unit and lane; the
 // weights W1r [w][tap][ci] in blocks of four hidden units.
 // LDS: slots [J][CIN][64] | stage [J][STAGE] | tiles [J][HC][SCW] (16-bit)
-template <int C>
-__global__ __launch_bounds__(512) void k_cond_bwd3(const bf16_t *__restrict__ g1t, const float *__restrict__ wt, float *__restrict__ dx,
+template <int C, class T>
+__global__ __launch_bounds__(512) void k_cond_bwd3(const T *__restrict__ g1t, const float *__restrict__ wt, float *__restrict__ dx,
                                                    CondShape s, int J, int NPXp)
 {
     constexpr int CIN = C / 2, K1 = 9 * CIN, NB = CIN <= 6 ? 16 : (CIN <= 12 ? 8 : 4); // hidden units per weight block
@@ -521,7 +525,7 @@ __global__ __launch_bounds__(512) void k_cond_bwd3(const bf16_t *__restrict__ g1
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     float *red = lds;
     float *wl = lds + J * CIN * 64 + wv * STAGE;
-    bf16_t *tile = (bf16_t *)(lds + J * CIN * 64 + J * STAGE) + (size_t)wv * HC * SCW;
+    T *tile = (T *)(lds + J * CIN * 64 + J * STAGE) + (size_t)wv * HC * SCW;
     const int HW = s.H * s.W, NPX = s.B * HW;
     const Pix q = pix_of(blockIdx.x * 64 + lane, HW, s.W, NPX);
     const float *__restrict__ w1r = wt + (size_t)K1 * s.Wd + (size_t)s.Wd * C + (size_t)18 * C * C + C;
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(512) void k_cond_bwd3(const bf16_t *__restrict__ g1
     auto blk = [&](int t) { return Blk{w1r + (size_t)(w0 + t * NB) * K1, NB * K1 / 4, 0}; };
     for (int t = 0; t < nblk; ++t) {
         const int jb = (t * NB) % HC; // position in the 16-unit tile
-        bf16_t v[HC][3];
+        T v[HC][3];
         if (jb == 0) { // the next 16 rows of g1t (SCW <= 3 * 64 for images up to 63 wide; wider ones take more rounds);
                        // clamped, unconditional loads (no branch per load), zeroed at the store
             const int wb = w0 + t * NB;
@@ -560,12 +564,12 @@ __global__ __launch_bounds__(512) void k_cond_bwd3(const bf16_t *__restrict__ g1
 #pragma unroll
                 for (int rr = 0; rr < 3; ++rr) {
                     const int e = lane + 64 * rr, pp = first + e;
-                    if (e < SCW) tile[j * SCW + e] = (pp >= 0 && pp < NPXp) ? v[j][rr] : (bf16_t)0;
+                    if (e < SCW) tile[j * SCW + e] = (pp >= 0 && pp < NPXp) ? v[j][rr] : (T)0;
                 }
             for (int e = lane + 192; e < SCW; e += 64) // images wider than 63 pixels
                 for (int j = 0; j < HC; ++j) {
                     const int pp = first + e;
-                    tile[j * SCW + e] = (pp >= 0 && pp < NPXp) ? g1t[(size_t)(wb + j) * NPXp + pp] : (bf16_t)0;
+                    tile[j * SCW + e] = (pp >= 0 && pp < NPXp) ? g1t[(size_t)(wb + j) * NPXp + pp] : (T)0;
                 }
         }
         __syncthreads();
@@ -620,25 +624,22 @@ template <int C> struct CondLaunch {
         IFL_HIP(hipGetLastError());
         return IFL_OK;
     }
-    static int backward(const float *x, const float *dh, const float *h, const float *a2, const float *wt, const float *w2,
-                        bf16_t *g3t, bf16_t *p3t, bf16_t *g2t, bf16_t *a1t, bf16_t *g1t, bf16_t *p1t, float *part, float *dx,
-                        CondShape s, float logscale, hipStream_t st)
+    template <class T>
+    static int backward(const float *x, const float *dh, const float *h, const float *a2, const float *wt, const float *w2, T *g3t,
+                        T *p3t, T *g2t, T *a1t, T *g1t, T *p1t, float *part, float *dx, CondShape s, float logscale, hipStream_t st)
     {
-        static LdsOptIn opt;
-        static LdsOptIn opt1;
+        static LdsOptIn opt1, opt2, opt3;
         const int NPX = s.B * s.H * s.W, tiles = (NPX + 63) / 64, J = pick_j(s.Wd), NPXp = tiles * 64;
         constexpr int JC = CSplit<C>::JC, ldsc = (JC * C * 64 + JC * STAGE) * (int)sizeof(float);
-        if (int rc = lds_opt_in(opt1, (const void *)k_cond_bwd1<C>, 160 * 1024 - 256)) return rc;
         const int lds2 = (K1 * 64 + J * STAGE + C * 64) * (int)sizeof(float);
-        const int lds3 = (J * (C / 2) * 64 + J * STAGE) * (int)sizeof(float) + J * HC * (64 + 2 * s.W + 2) * (int)sizeof(bf16_t);
-        static LdsOptIn opt3;
+        const int lds3 = (J * (C / 2) * 64 + J * STAGE) * (int)sizeof(float) + J * HC * (64 + 2 * s.W + 2) * (int)sizeof(T);
         if (lds3 > 160 * 1024 - 256) IFL_FAIL(IFL_EUNSUPPORTED, "ifl_cond_backward_f32: images of width %d are too wide", s.W);
-        if (int rc = lds_opt_in(opt, (const void *)k_cond_bwd2<C>, 160 * 1024 - 256)) return rc;
-        if (int rc = lds_opt_in(opt3, (const void *)k_cond_bwd3<C>, 160 * 1024 - 256)) return rc;
-        hipLaunchKernelGGL(k_cond_bwd1<C>, dim3(tiles), dim3(64 * JC), ldsc, st, dh, h, a2, wt, g3t, p3t, g2t, part, s, NPXp, logscale);
-        hipLaunchKernelGGL(k_cond_bwd2<C>, dim3(tiles), dim3(64 * J), lds2, st, x, (const bf16_t *)g2t, wt, w2, a1t, g1t, p1t, s, J,
-                           NPXp);
-        hipLaunchKernelGGL(k_cond_bwd3<C>, dim3(tiles), dim3(64 * J), lds3, st, (const bf16_t *)g1t, wt, dx, s, J, NPXp);
+        if (int rc = lds_opt_in(opt1, (const void *)k_cond_bwd1<C, T>, 160 * 1024 - 256)) return rc;
+        if (int rc = lds_opt_in(opt2, (const void *)k_cond_bwd2<C, T>, 160 * 1024 - 256)) return rc;
+        if (int rc = lds_opt_in(opt3, (const void *)k_cond_bwd3<C, T>, 160 * 1024 - 256)) return rc;
+        hipLaunchKernelGGL((k_cond_bwd1<C, T>), dim3(tiles), dim3(64 * JC), ldsc, st, dh, h, a2, wt, g3t, p3t, g2t, part, s, NPXp, logscale);
+        hipLaunchKernelGGL((k_cond_bwd2<C, T>), dim3(tiles), dim3(64 * J), lds2, st, x, (const T *)g2t, wt, w2, a1t, g1t, p1t, s, J, NPXp);
+        hipLaunchKernelGGL((k_cond_bwd3<C, T>), dim3(tiles), dim3(64 * J), lds3, st, (const T *)g1t, wt, dx, s, J, NPXp);
         IFL_HIP(hipGetLastError());
         return IFL_OK;
     }
@@ -704,7 +705,7 @@ int ifl_cond_forward_f32(const float *x, int x_channels, const float *wt, const 
 }
 
 int ifl_cond_backward_f32(const float *x, int x_channels, const float *dh, const float *h, const float *a2, const float *wt,
-                          const float *w2, uint16_t *g3t, uint16_t *p3t, uint16_t *g2t, uint16_t *a1t, uint16_t *g1t, uint16_t *p1t,
+                          const float *w2, void *g3t, void *p3t, void *g2t, void *a1t, void *g1t, void *p1t, int operands_f32,
                           float *part, float *dx, int B, int C, int H, int W, int width, float logscale_factor,
                           ifl_stream_t stream)
 {
@@ -714,8 +715,13 @@ int ifl_cond_backward_f32(const float *x, int x_channels, const float *dh, const
     if (!x || !dh || !h || !a2 || !wt || !w2 || !g3t || !p3t || !g2t || !a1t || !g1t || !p1t || !part || !dx)
         IFL_FAIL(IFL_EINVAL, "ifl_cond_backward_f32: null pointer");
     const CondShape s{B, H, W, width, x_channels};
-    IFL_COND_DISPATCH(C, backward(x, dh, h, a2, wt, w2, g3t, p3t, g2t, a1t, g1t, p1t, part, dx, s, logscale_factor,
-                                  (hipStream_t)stream));
+    hipStream_t st = (hipStream_t)stream;
+    if (operands_f32) {
+        IFL_COND_DISPATCH(C, backward(x, dh, h, a2, wt, w2, (float *)g3t, (float *)p3t, (float *)g2t, (float *)a1t, (float *)g1t,
+                                      (float *)p1t, part, dx, s, logscale_factor, st));
+    }
+    IFL_COND_DISPATCH(C, backward(x, dh, h, a2, wt, w2, (bf16_t *)g3t, (bf16_t *)p3t, (bf16_t *)g2t, (bf16_t *)a1t, (bf16_t *)g1t,
+                                  (bf16_t *)p1t, part, dx, s, logscale_factor, st));
 }
 
 } // extern "C"

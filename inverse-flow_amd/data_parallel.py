@@ -61,13 +61,30 @@ class GradBucket:
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        off = 0
+        off, self.views = 0, []
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            p.grad = self.views[-1]
             off += p.numel()
 
     def zero(self):
         self.flat.zero_()
+
+    def release(self):
+        """detach the parameters from the bucket for one backward pass: their gradients arrive in fresh tensors"""
+        for p in self.params:
+            p.grad = None
+
+    def gather(self):
+        """the fresh gradients into the bucket with one multi-tensor copy (parameters that received none: zeros), and the
+        parameters' .grad back onto their bucket views"""
+        got = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
+        if len(got) != len(self.params):
+            self.flat.zero_()
+        if got:
+            torch._foreach_copy_([v for v, _ in got], [g for _, g in got])
+        for v, p in zip(self.views, self.params):
+            p.grad = v
 
     def allreduce_mean(self, async_op=False, force=False):
         """Sum over ranks, divide by the world size.  Returns the work handle when async_op.  force: issue the collective in

@@ -68,16 +68,17 @@ class _Affine(torch.autograd.Function):
 class _CondAffine(torch.autograd.Function):
     """(x, the conditioner's parameters) -> (y, sum log_s): conditioner and affine map on the library, forward and backward
     (csrc/conditioner.hip: two launches for h = net(x1), three + three GEMMs for its backward, next to the affine map's
-    one each way).  fp32 throughout -- under autocast too: the net's arithmetic is small, its launch count is not."""
+    one each way).  fp32 arithmetic throughout -- under autocast too: the net's arithmetic is small, its launch count is
+    not; `lowp` (autocast on) only picks bf16 operand matrices for the three weight-gradient GEMMs."""
 
     @staticmethod
     @_fwd32
-    def forward(ctx, x, w1, w2, w3, b3, logs, logscale):
+    def forward(ctx, x, w1, w2, w3, b3, logs, logscale, lowp):
         x = x.contiguous()
         wt = H.cond_prep(w1.contiguous(), w2.contiguous(), w3.contiguous(), logs.contiguous(), logscale)
         a2, h = H.cond_forward(x, wt, b3, w3.shape[0], w1.shape[0])
         ctx.save_for_backward(x, h, a2, wt, w2)
-        ctx.logscale, ctx.has_bias = logscale, b3 is not None
+        ctx.logscale, ctx.has_bias, ctx.lowp = logscale, b3 is not None, lowp
         return H.coupling(x, h)
 
     @staticmethod
@@ -85,8 +86,8 @@ class _CondAffine(torch.autograd.Function):
     def backward(ctx, gy, gld):
         x, h, a2, wt, w2 = ctx.saved_tensors
         gx, gh = H.coupling_backward(gy.contiguous(), gld.contiguous() if gld is not None else None, x, h)
-        dw1, dw2, dw3, dlogs, db3 = H.cond_backward(x, gh, h, a2, wt, w2.contiguous(), gx, w2.shape[1], ctx.logscale)
-        return gx, dw1, dw2, dw3, (db3 if ctx.has_bias else None), dlogs, None
+        dw1, dw2, dw3, dlogs, db3 = H.cond_backward(x, gh, h, a2, wt, w2.contiguous(), gx, w2.shape[1], ctx.logscale, ctx.lowp)
+        return gx, dw1, dw2, dw3, (db3 if ctx.has_bias else None), dlogs, None, None
 
 
 def _on_library(x):
@@ -153,7 +154,9 @@ class Coupling(FlowLayer):
     def forward(self, input, context=None):
         if self._fusable(input, context):
             c1, c2, c3 = self.net[0], self.net[2], self.net[4]
-            return _CondAffine.apply(input, c1.weight, c2.weight, c3.weight, c3.bias, c3.logs, c3.logscale_factor)
+            # (under bf16 autocast the weight gradients' GEMMs take bf16 operands -- the step's precision; fp32 otherwise)
+            return _CondAffine.apply(input, c1.weight, c2.weight, c3.weight, c3.bias, c3.logs, c3.logscale_factor,
+                                     torch.is_autocast_enabled("cuda"))
         if _on_library(input):
             return _Affine.apply(input, self._conditioner(input, context))
         x1, x2, log_s, t = self.get_xs_logs_t(input, context)

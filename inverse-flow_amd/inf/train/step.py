@@ -48,7 +48,7 @@ class TrainStep:
 
     def __init__(self, model, optimizer, add_recon_grad=False, grad_clip_norm=None, grad_clip=None, clear_grads=False,
                  autocast=False, bucket=True, graph=False, graph_warmup=3, force_collective=False, conv_search=False,
-                 fused_optimizer=True):
+                 fused_optimizer=True, gather_grads=None):
         self.model, self.optimizer = model, optimizer
         self.add_recon_grad, self.grad_clip_norm, self.grad_clip = add_recon_grad, grad_clip_norm, grad_clip
         self.clear_grads, self.autocast = clear_grads, autocast
@@ -57,6 +57,7 @@ class TrainStep:
         self.bucket = dp.GradBucket(model.parameters()) if bucket else None
         self._n_params = sum(1 for _ in model.parameters())
         self.graph, self.graph_warmup = graph, graph_warmup
+        self.gather_grads = graph if gather_grads is None else gather_grads
         self._calls, self._captured, self._static_x, self._static_loss, self._stream = 0, None, None, None, None
         self._captured2, self._split = None, False
         self._ranks_agree = False  # data-dependent initialisations (ActNorm) made identical on every rank
@@ -186,13 +187,21 @@ class TrainStep:
         return self._static_loss.clone()
 
     def _backward_part(self, x):
-        if self.bucket is not None:
+        gather = self.bucket is not None and self.gather_grads and x.is_cuda
+        if gather:
+            # backward into fresh tensors (autograd keeps the tensor a parameter's first gradient arrives in: no kernel),
+            # then ONE multi-tensor copy into the flat bucket -- instead of one accumulation kernel per parameter into its
+            # zeroed bucket view (290 launches a step for the configs[3] model)
+            self.bucket.release()
+        elif self.bucket is not None:
             self.bucket.zero()
         else:
             self.optimizer.zero_grad()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.autocast and x.is_cuda):
             lossval = get_loss(self.model, x)
         lossval.backward()
+        if gather:
+            self.bucket.gather()
         if self.add_recon_grad:  # experiment.py:284-285 (the SelfNormConv layers' reconstruction term)
             self.model.add_recon_grad()
         if self.clear_grads:  # experiment.py:255 (the reference does this on its 'test' branch only)

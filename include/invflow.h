@@ -257,7 +257,7 @@ int ifl_coupling_backward_bf16(const uint16_t *gy, const float *g_logdet, const 
  * h = (W3 * relu(W2 relu(W1 * x1)) + b3) exp(logscale_factor logs): 3x3 conv C/2 -> width (no bias), ReLU, 1x1 conv
  * width -> C (no bias), ReLU, 3x3 conv C -> C with bias and a per-channel gain, zero padding 1.  x1 = the first C/2
  * channels of x (an NCHW tensor of x_channels >= C/2 channels: the coupling's input as it is, no slice copy); everything
- * fp32 NCHW.  Two launches forward, three backward plus three GEMMs that stay with the caller (see below); a model's step
+ * fp32 NCHW.  Two launches forward, six backward; a model's step
  * calls this per coupling in place of some fifty library-convolution launches.  C in {4, 8, 12, 16, 24, 32, 48}, width a
  * multiple of 16 (ifl_cond_supported); other shapes: IFL_EUNSUPPORTED, and the host layer keeps its convolutions.
  *
@@ -266,15 +266,10 @@ int ifl_coupling_backward_bf16(const uint16_t *gy, const float *g_logdet, const 
  * ifl_cond_forward_f32: a2 [B][C][H][W] (the second ReLU's output, kept for the backward) and h [B][C][H][W].
  * ifl_cond_backward_f32 (dh = gradient of h):
  *   dx[:, :C/2] += the input gradient (dx: [B][x_channels][H][W], already holding the coupling's direct part);
- *   part [tiles][2C], tiles = P/64, P = ifl_cond_pixels_padded(B,H,W): per-tile sums -- column sums give d logs (first C)
- *     and d b3 (last C);
- *   the operands of the weight gradients as matrices with P columns (pixel-major, zero in the padding), bf16 (operands_f32
- *   = 0: the precision of a bf16 autocast step) or fp32 (operands_f32 = 1: an fp32 step keeps fp32-accurate gradients; the
- *   input gradient goes through g1t and follows the same choice):
- *     g3t [C][P], p3t [9C][P]:    dW3 [C][C*9]       = g3t p3t^T
- *     g2t [C][P], a1t [width][P]: dW2 [C][width]     = g2t a1t^T
- *     g1t [width][P], p1t [9C/2][P]: dW1 [width][C/2*9] = g1t p1t^T
- *   (long reductions with small outputs: library GEMMs; the host layer issues them with fp32 outputs).
+ *   grads [ifl_cond_grads_floats(C, width)] = dW1 [width][C/2][3][3] | dW2 [C][width] | dW3 [C][C][3][3] | d logs [C] | d b3 [C];
+ *   ws: ifl_cond_backward_workspace_bytes(...) bytes, 256-aligned (the operand matrices of the weight-gradient products,
+ *   pixel-major, and the partial sums).  operands_f32 = 0: those matrices are bf16 (fp32 accumulate: the precision of a
+ *   bf16 autocast step); 1: fp32 (an fp32 step keeps fp32-accurate gradients).  Six launches.
  * No float atomics anywhere: results are reproducible bit for bit. */
 int ifl_cond_supported(int C, int width);
 size_t ifl_cond_weights_floats(int C, int width);
@@ -283,10 +278,11 @@ int ifl_cond_prep_f32(const float *w1, const float *w2, const float *w3, const f
                       float logscale_factor, ifl_stream_t stream);
 int ifl_cond_forward_f32(const float *x, int x_channels, const float *wt, const float *b3, float *a2, float *h, int B, int C, int H,
                          int W, int width, ifl_stream_t stream);
+size_t ifl_cond_backward_workspace_bytes(int B, int C, int H, int W, int width, int operands_f32);
+size_t ifl_cond_grads_floats(int C, int width);
 int ifl_cond_backward_f32(const float *x, int x_channels, const float *dh, const float *h, const float *a2, const float *wt,
-                          const float *w2, void *g3t, void *p3t, void *g2t, void *a1t, void *g1t, void *p1t, int operands_f32,
-                          float *part, float *dx, int B, int C, int H, int W, int width, float logscale_factor,
-                          ifl_stream_t stream);
+                          const float *w2, int operands_f32, void *ws, size_t ws_bytes, float *grads, float *dx, int B, int C, int H,
+                          int W, int width, float logscale_factor, ifl_stream_t stream);
 
 /* ---- activations of the Glow step (inf/layers/activations.py) ----------------------------------------------------- */
 size_t ifl_activation_workspace_bytes(int B, int C, int n_bins); /* scratch of the calls below (n_bins = 0: SmoothLeakyRelu) */

@@ -1,6 +1,6 @@
 // The conditioner of the affine coupling (inf/layers/coupling.py:47-62: `Coupling.net` = 3x3 conv C/2 -> width, ReLU,
 // 1x1 conv width -> C, ReLU, Conv2dZero C -> C = 3x3 conv + bias, times exp(3 logs) per channel: coupling.py:9-45), forward
-// and backward: two launches forward, three backward.
+// and backward: two launches forward, six backward.
 //
 // Why it is here: the three convolutions are tiny (C <= 48 channels on <= 16x16 images; 0.05-0.5 GFLOP) and a training step
 // of the configs[2]/[3]/[4] models runs 33-150 of these nets.  On library convolutions one net is ~55 launches forward +
@@ -12,10 +12,10 @@
 //             k_cond_fwd2   h  = (W3 * a2 + b3) exp(3 logs)
 //   backward  k_cond_bwd1   g3 = dh gain, d logs, d b3, g2 = relu'(a2) (W3^T * g3), and the two operand matrices of dW3
 //             k_cond_bwd2   hidden activation recomputed, g1 = relu'(a1) W2^T g2, and the operand matrices of dW1, dW2
-//             k_cond_bwd3   dx1 += W1^T * g1 (3x3 transposed: a gather over the g1 rows just written)
-//   the three weight gradients are then [rows x pixels] @ [pixels x cols] products with a long reduction and a small
-//   output -- plain library GEMMs (hipBLASLt through torch.mm on the host side: 5-30 us each), fed by 16-bit operand
-//   matrices these kernels write pixel-major (coalesced).
+//             k_cond_bwd3u  u = W1^T g1 per pixel and tap, on the fp32 matrix cores;  k_cond_bwd3g  dx1 += the nine taps of u
+//             k_cond_wgrad  the three weight gradients: [rows x pixels] x [pixels x cols] products with a long reduction and a
+//                           small output, from operand matrices the kernels above write pixel-major; k_cond_wreduce adds its
+//                           slices (and the per-tile sums of d logs, d b3)
 //
 // Arithmetic: fp32 FMA on the fp32 master weights (nothing is cast per step).  A workgroup owns 64 pixels (a lane = a
 // pixel) and splits the reduction index -- hidden units, or input channels of the 3x3 over C -- over its J <= 8 waves,
@@ -509,93 +509,257 @@ __global__ __launch_bounds__(512) void k_cond_bwd2(const float *__restrict__ x, 
     }
 }
 
-// ---- backward 3: dx[:, :C/2] += W1^T * g1 -----------------------------------------------------------------------------------
-// dx1[ci][p] = sum_{w,tap} W1[w][ci][tap] g1[w][p - (dy-1) W - (dx-1)]: the rows of g1t around the tile staged 16 hidden units
-// at a time in LDS (64 + 2W + 2 pixels each, one tile per wave), nine reads and 9 C/2 FMAs per hidden unit and lane; the
-// weights W1r [w][tap][ci] in blocks of four hidden units.
-// LDS: slots [J][CIN][64] | stage [J][STAGE] | tiles [J][HC][SCW] (16-bit)
+// ---- backward 3: dx[:, :C/2] += W1^T * g1 (3x3, transposed) ------------------------------------------------------------------
+// Two steps.  (a) u[k][p] = sum_w W1[w][k] g1[w][p], k = ci*9 + tap: what pixel p sends to its neighbour at `tap` -- a
+// [9C/2 x width] x [width x pixels] product on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, the vector FMA
+// rate, but operands come as fragments: 2 LDS words per 1024 MACs where the broadcast-weight FMA form reads 17 -- that
+// form was LDS-bound at 40-120 us).  A workgroup owns 64 pixels and all of k; width goes through LDS in chunks of 32
+// hidden units (W1t rows and g1t rows, loaded for the next chunk while this one is multiplied); its eight waves split
+// the k tiles, and the hidden units of a chunk where there are fewer than eight k tiles.  (b) dx1[ci][p] = sum_tap
+// u[ci*9+tap][p - offset(tap)]: nine reads per element.
+template <int C> struct UCfg {
+    static constexpr int K1 = 9 * (C / 2), MT = (K1 + 15) / 16, K1P = MT * 16;
+    static constexpr int MS = MT >= 8 ? 8 : (MT >= 4 ? 4 : (MT >= 2 ? 2 : 1)), KS = 8 / MS; // waves = MS x KS
+    static constexpr int MW = (MT + MS - 1) / MS;                                          // k tiles of a wave
+    static constexpr int WCH = 32, AST = WCH + 1, BST = 64 + 16;                           // chunk, padded LDS row strides
+    static constexpr int A_FL = K1P * AST, B_FL = WCH * BST;
+    static constexpr int NA = (K1P * WCH + 511) / 512, NBL = WCH * 64 / 512;               // elements per thread and chunk
+    static constexpr int SLOT_FL = KS > 1 ? 8 * MW * 4 * 256 : 0, LDS_FL = A_FL + B_FL > SLOT_FL ? A_FL + B_FL : SLOT_FL;
+};
+
 template <int C, class T>
-__global__ __launch_bounds__(512) void k_cond_bwd3(const T *__restrict__ g1t, const float *__restrict__ wt, float *__restrict__ dx,
-                                                   CondShape s, int J, int NPXp)
+__global__ __launch_bounds__(512) void k_cond_bwd3u(const T *__restrict__ g1t, const float *__restrict__ wt, float *__restrict__ u,
+                                                    int Wd, int NPXp)
 {
-    constexpr int CIN = C / 2, K1 = 9 * CIN, NB = CIN <= 6 ? 16 : (CIN <= 12 ? 8 : 4); // hidden units per weight block
-    static_assert(NB * K1 <= STAGE && HC % NB == 0, "a block of hidden units' weights fits the stage");
+    using U = UCfg<C>;
+    constexpr int K1 = U::K1, MS = U::MS, KS = U::KS, MW = U::MW, WCH = U::WCH, AST = U::AST, BST = U::BST;
     extern __shared__ float lds[];
-    const int SCW = 64 + 2 * s.W + 2;
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    float *red = lds;
-    float *wl = lds + J * CIN * 64 + wv * STAGE;
-    T *tile = (T *)(lds + J * CIN * 64 + J * STAGE) + (size_t)wv * HC * SCW;
-    const int HW = s.H * s.W, NPX = s.B * HW;
-    const Pix q = pix_of(blockIdx.x * 64 + lane, HW, s.W, NPX);
-    const float *__restrict__ w1r = wt + (size_t)K1 * s.Wd + (size_t)s.Wd * C + (size_t)18 * C * C + C;
-    unsigned okb = 0;
+    float *As = lds, *Bs = lds + U::A_FL;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ms = wv % MS, ks = wv / MS;
+    const int p0 = blockIdx.x * 64;
+    const float *__restrict__ w1t = wt; // [K1][Wd]
+    float ra[U::NA], rb[U::NBL];
+    auto load = [&](int w0) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int yy = q.y - (tap / 3 - 1), xx = q.x - (tap % 3 - 1);
-        if (q.live && yy >= 0 && yy < s.H && xx >= 0 && xx < s.W) okb |= 1u << tap;
-    }
-    float acc[CIN];
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) acc[c] = 0.f;
-    const int first = blockIdx.x * 64 - (s.W + 1); // flattened pixel of tile entry 0
-    const int per = s.Wd / J, w0 = wv * per, nblk = per / NB;
-    auto blk = [&](int t) { return Blk{w1r + (size_t)(w0 + t * NB) * K1, NB * K1 / 4, 0}; };
-    for (int t = 0; t < nblk; ++t) {
-        const int jb = (t * NB) % HC; // position in the 16-unit tile
-        T v[HC][3];
-        if (jb == 0) { // the next 16 rows of g1t (SCW <= 3 * 64 for images up to 63 wide; wider ones take more rounds);
-                       // clamped, unconditional loads (no branch per load), zeroed at the store
-            const int wb = w0 + t * NB;
-#pragma unroll
-            for (int j = 0; j < HC; ++j)
-#pragma unroll
-                for (int rr = 0; rr < 3; ++rr) {
-                    const int pp = min(max(first + lane + 64 * rr, 0), NPXp - 1);
-                    v[j][rr] = g1t[(size_t)(wb + j) * NPXp + pp];
-                }
+        for (int i = 0; i < U::NA; ++i) { // A chunk: rows k (zero past K1), 32 consecutive w
+            const int e = tid + 512 * i, k = e / WCH, w = e % WCH;
+            const int kc = k < K1 ? k : K1 - 1, wc = w0 + w < Wd ? w0 + w : Wd - 1; // (width is a multiple of 16, not of 32)
+            const float v = w1t[(size_t)kc * Wd + wc];
+            ra[i] = (e < U::K1P * WCH && k < K1 && w0 + w < Wd) ? v : 0.f;
         }
-        __syncthreads();
-        blk_copy(wl, blk(t), lane);
-        if (jb == 0) {
-            const int wb = w0 + t * NB;
 #pragma unroll
-            for (int j = 0; j < HC; ++j)
-#pragma unroll
-                for (int rr = 0; rr < 3; ++rr) {
-                    const int e = lane + 64 * rr, pp = first + e;
-                    if (e < SCW) tile[j * SCW + e] = (pp >= 0 && pp < NPXp) ? v[j][rr] : (T)0;
-                }
-            for (int e = lane + 192; e < SCW; e += 64) // images wider than 63 pixels
-                for (int j = 0; j < HC; ++j) {
-                    const int pp = first + e;
-                    tile[j * SCW + e] = (pp >= 0 && pp < NPXp) ? g1t[(size_t)(wb + j) * NPXp + pp] : (T)0;
-                }
+        for (int i = 0; i < U::NBL; ++i) { // B chunk: 32 rows of g1t, this tile's 64 pixels
+            const int e = tid + 512 * i, w = e / 64, px = e % 64;
+            const float v = widen(g1t[(size_t)(w0 + w < Wd ? w0 + w : Wd - 1) * NPXp + p0 + px]);
+            rb[i] = w0 + w < Wd ? v : 0.f;
         }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int i = 0; i < U::NA; ++i) {
+            const int e = tid + 512 * i, k = e / WCH, w = e % WCH;
+            if (e < U::K1P * WCH) As[k * AST + w] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < U::NBL; ++i) {
+            const int e = tid + 512 * i, w = e / 64, px = e % 64;
+            Bs[w * BST + px] = rb[i];
+        }
+    };
+    f4 acc[MW][4];
+#pragma unroll
+    for (int m = 0; m < MW; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f4{0.f, 0.f, 0.f, 0.f};
+    load(0);
+    for (int w0 = 0; w0 < Wd; w0 += WCH) {
         __syncthreads();
-#pragma unroll 1
-        for (int j = 0; j < NB; ++j) {
-            float gvv[9];
+        store();
+        __syncthreads();
+        if (w0 + WCH < Wd) load(w0 + WCH);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
-                gvv[tap] = (okb >> tap) & 1 ? widen(tile[(jb + j) * SCW + lane + (2 - tap / 3) * s.W + (2 - tap % 3)]) : 0.f;
+        for (int st = 0; st < WCH / 4 / KS; ++st) {
+            const int kk = 4 * (ks + KS * st) + (lane >> 4); // hidden unit of this lane's fragment element
+            float bf[4];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const float *wr = wl + (j * 9 + tap) * CIN;
+            for (int n = 0; n < 4; ++n) bf[n] = Bs[kk * BST + 16 * n + (lane & 15)];
 #pragma unroll
-                for (int ci = 0; ci < CIN; ++ci) acc[ci] = fmaf(wr[ci], gvv[tap], acc[ci]);
+            for (int m = 0; m < MW; ++m) {
+                const int mt = ms + MS * m;
+                if (mt < U::MT) {
+                    const float af = As[(16 * mt + (lane & 15)) * AST + kk];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[n], acc[m][n], 0, 0, 0);
+                }
             }
         }
     }
+    // sum over the KS hidden-unit groups (LDS slots, group order), then u[k][p]
+    if (KS > 1) {
+        __syncthreads();
+        f4 *slot = (f4 *)lds; // [ks][ms-local tile m][n][lane]
 #pragma unroll
-    for (int ci = 0; ci < CIN; ++ci) red[(wv * CIN + ci) * 64 + lane] = acc[ci];
-    __syncthreads();
-    if (q.live)
-        for (int ci = wv; ci < CIN; ci += J) {
-            float t = 0.f;
-            for (int j = 0; j < J; ++j) t += red[(j * CIN + ci) * 64 + lane];
-            dx[((size_t)q.b * s.Cx + ci) * HW + q.r] += t;
+        for (int m = 0; m < MW; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) slot[((wv * MW + m) * 4 + n) * 64 + lane] = acc[m][n];
+        __syncthreads();
+        if (ks == 0) {
+#pragma unroll
+            for (int m = 0; m < MW; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    f4 t = acc[m][n];
+                    for (int g = 1; g < KS; ++g) t += slot[(((g * MS + ms) * MW + m) * 4 + n) * 64 + lane];
+                    acc[m][n] = t;
+                }
         }
+    }
+    if (ks == 0) {
+#pragma unroll
+        for (int m = 0; m < MW; ++m) {
+            const int mt = ms + MS * m;
+            if (mt < U::MT) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = 16 * mt + 4 * (lane >> 4) + r;
+                        if (k < K1) u[(size_t)k * NPXp + p0 + 16 * n + (lane & 15)] = acc[m][n][r];
+                    }
+            }
+        }
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void k_cond_bwd3g(const float *__restrict__ u, float *__restrict__ dx, CondShape s, int NPXp)
+{
+    constexpr int CIN = C / 2;
+    const int HW = s.H * s.W, NPX = s.B * HW;
+    const int lane = threadIdx.x & 63, ci0 = threadIdx.x >> 6;
+    const Pix q = pix_of(blockIdx.x * 64 + lane, HW, s.W, NPX);
+    int off[9];
+    const unsigned okb = nine_offsets(off, q, s, -1); // the pixel whose tap lands here: p - (dy-1) W - (dx-1)
+    for (int ci = ci0; ci < CIN; ci += 4) {
+        float t = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float v = u[(size_t)(ci * 9 + tap) * NPXp + (q.live ? q.p : 0) + off[tap]];
+            t += (okb >> tap) & 1 ? v : 0.f;
+        }
+        if (q.live) dx[((size_t)q.b * s.Cx + ci) * HW + q.r] += t;
+    }
+}
+
+// ---- the three weight gradients: out[m][n] = sum_p A[m][p] B[n][p] -----------------------------------------------------------
+// dW1 = g1t p1t^T [Wd x 9C/2], dW2 = g2t a1t^T [C x Wd], dW3 = g3t p3t^T [C x 9C]: reductions over all P pixels with small
+// outputs.  (Library GEMMs take 8-50 us EACH for these shapes -- a third of the configs[2] step.)  One launch for all
+// three: a wave owns a 16x16 output tile and a slice of 512 pixels -- bf16 operands on v_mfma_f32_16x16x16_bf16, fp32
+// operands on v_mfma_f32_16x16x4_f32, a lane's fragment 8 / 4 bytes straight from the row-major operand matrices (both
+// operands are [row][pixel]: the same access pattern) -- and writes its partial tile; k_cond_wreduce adds the slices in
+// order (and the per-tile sums of d logs / d b3): deterministic.
+struct WJob {
+    const void *A, *B;
+    int M, N, nt, blk0; // nt: tiles along N; blk0: first (tile) index of this job in the grid
+    size_t out;         // offset of the job's output in a slice
+};
+struct WJobs {
+    WJob j[3];
+};
+static constexpr int WSL = 512; // pixels per slice
+
+typedef short short4_ __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f4 wfrag_mma(const bf16_t *ar, const bf16_t *br, bool aon, bool bon, int p0, int p1, int lane)
+{
+    f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+    // (the reduction index may be permuted as long as both operands agree: within a chunk of 64 pixels a lane takes 16
+    // CONSECUTIVE pixels -- 32 / 64 contiguous bytes per lane instead of 8 / 4 bytes at four / sixteen places)
+    const int q16 = 16 * (lane >> 4);
+    for (int p = p0; p < p1; p += 64) { // (P is a multiple of 64)
+        short4_ a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i] = *(const short4_ *)(ar + p + q16 + 4 * i);
+            b[i] = *(const short4_ *)(br + p + q16 + 4 * i);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (!aon) a[i] = short4_{0, 0, 0, 0};
+            if (!bon) b[i] = short4_{0, 0, 0, 0};
+            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[i], b[i], acc, 0, 0, 0);
+        }
+    }
+    return acc;
+}
+__device__ __forceinline__ f4 wfrag_mma(const float *ar, const float *br, bool aon, bool bon, int p0, int p1, int lane)
+{
+    f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+    const int q16 = 16 * (lane >> 4);
+    for (int p = p0; p < p1; p += 64) {
+        float a[16], b[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            a[i] = ar[p + q16 + i];
+            b[i] = br[p + q16 + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aon ? a[i] : 0.f, bon ? b[i] : 0.f, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+template <class T>
+__global__ __launch_bounds__(64) void k_cond_wgrad(WJobs jobs, float *__restrict__ gpart, int P, int S, size_t per_slice)
+{
+    const int lane = threadIdx.x, sl = blockIdx.x % S, tile = blockIdx.x / S;
+    const int ji = tile >= jobs.j[2].blk0 ? 2 : (tile >= jobs.j[1].blk0 ? 1 : 0);
+    const WJob jb = jobs.j[ji];
+    const int t = tile - jb.blk0, mt = t / jb.nt, nt = t % jb.nt;
+    const int am = 16 * mt + (lane & 15), bn = 16 * nt + (lane & 15);
+    const T *ar = (const T *)jb.A + (size_t)min(am, jb.M - 1) * P, *br = (const T *)jb.B + (size_t)min(bn, jb.N - 1) * P;
+    const int p0 = sl * WSL, p1 = min(P, p0 + WSL);
+    const f4 acc = wfrag_mma(ar, br, am < jb.M, bn < jb.N, p0, p1, lane);
+    float *o = gpart + (size_t)sl * per_slice + jb.out;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = 16 * mt + 4 * (lane >> 4) + r, n = 16 * nt + (lane & 15);
+        if (m < jb.M && n < jb.N) o[(size_t)m * jb.N + n] = acc[r];
+    }
+}
+
+// out[i] = sum_s gpart[s][i] (i < per_slice: dW1 | dW2 | dW3), out[per_slice + c] = sum_tiles tpart[tile][c] (c < 2C: d logs | d b3)
+__global__ __launch_bounds__(256) void k_cond_wreduce(const float *__restrict__ gpart, const float *__restrict__ tpart,
+                                                      float *__restrict__ out, size_t per_slice, int S, int tiles, int C2)
+{
+    const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (i < per_slice) {
+        float t = 0.f;
+        int sl = 0;
+        for (; sl + 8 <= S; sl += 8) { // (eight loads in flight, added in slice order)
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = gpart[(size_t)(sl + k) * per_slice + i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += v[k];
+        }
+        for (; sl < S; ++sl) t += gpart[(size_t)sl * per_slice + i];
+        out[i] = t;
+    } else if (i < per_slice + C2) {
+        const int c = (int)(i - per_slice);
+        float t = 0.f;
+        int k = 0;
+        for (; k + 8 <= tiles; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = tpart[(size_t)(k + j) * C2 + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t += v[j];
+        }
+        for (; k < tiles; ++k) t += tpart[(size_t)k * C2 + c];
+        out[i] = t;
+    }
 }
 
 // hidden units are split over J waves: as many as divide them into whole chunks, up to 8 (work per wave is small and latency
@@ -605,6 +769,23 @@ static int pick_j(int Wd)
     int J = 1;
     while (J < 8 && Wd % (2 * J * HC) == 0) J *= 2;
     return J;
+}
+
+// workspace of the backward (byte offsets, 256-aligned): operand matrices | u | per-tile sums | per-slice partial gradients
+struct CondWs {
+    size_t ops, u, tpart, gpart, per_slice, total;
+};
+static CondWs cond_ws(int C, int Wd, int P, size_t elem)
+{
+    CondWs w;
+    const size_t K1 = 9 * (size_t)(C / 2), S = ((size_t)P + WSL - 1) / WSL;
+    w.per_slice = (size_t)Wd * K1 + (size_t)C * Wd + (size_t)9 * C * C;
+    w.ops = 0;
+    w.u = align_up(w.ops + ((size_t)11 * C + 2 * (size_t)Wd + K1) * P * elem, 256);
+    w.tpart = align_up(w.u + K1 * P * sizeof(float), 256);
+    w.gpart = align_up(w.tpart + (size_t)(P / 64) * 2 * C * sizeof(float), 256);
+    w.total = align_up(w.gpart + S * w.per_slice * sizeof(float), 256);
+    return w;
 }
 
 template <int C> struct CondLaunch {
@@ -625,21 +806,36 @@ template <int C> struct CondLaunch {
         return IFL_OK;
     }
     template <class T>
-    static int backward(const float *x, const float *dh, const float *h, const float *a2, const float *wt, const float *w2, T *g3t,
-                        T *p3t, T *g2t, T *a1t, T *g1t, T *p1t, float *part, float *dx, CondShape s, float logscale, hipStream_t st)
+    static int backward(const float *x, const float *dh, const float *h, const float *a2, const float *wt, const float *w2, void *ws,
+                        float *grads, float *dx, CondShape s, float logscale, hipStream_t st)
     {
         static LdsOptIn opt1, opt2, opt3;
-        const int NPX = s.B * s.H * s.W, tiles = (NPX + 63) / 64, J = pick_j(s.Wd), NPXp = tiles * 64;
+        const int NPX = s.B * s.H * s.W, tiles = (NPX + 63) / 64, J = pick_j(s.Wd), P = tiles * 64;
+        const CondWs w = cond_ws(C, s.Wd, P, sizeof(T));
+        char *b = (char *)ws;
+        T *g3t = (T *)(b + w.ops), *p3t = g3t + (size_t)C * P, *g2t = p3t + (size_t)9 * C * P, *a1t = g2t + (size_t)C * P;
+        T *g1t = a1t + (size_t)s.Wd * P, *p1t = g1t + (size_t)s.Wd * P;
+        float *u = (float *)(b + w.u), *tpart = (float *)(b + w.tpart), *gpart = (float *)(b + w.gpart);
         constexpr int JC = CSplit<C>::JC, ldsc = (JC * C * 64 + JC * STAGE) * (int)sizeof(float);
         const int lds2 = (K1 * 64 + J * STAGE + C * 64) * (int)sizeof(float);
-        const int lds3 = (J * (C / 2) * 64 + J * STAGE) * (int)sizeof(float) + J * HC * (64 + 2 * s.W + 2) * (int)sizeof(T);
-        if (lds3 > 160 * 1024 - 256) IFL_FAIL(IFL_EUNSUPPORTED, "ifl_cond_backward_f32: images of width %d are too wide", s.W);
+        constexpr int lds3 = UCfg<C>::LDS_FL * (int)sizeof(float);
         if (int rc = lds_opt_in(opt1, (const void *)k_cond_bwd1<C, T>, 160 * 1024 - 256)) return rc;
         if (int rc = lds_opt_in(opt2, (const void *)k_cond_bwd2<C, T>, 160 * 1024 - 256)) return rc;
-        if (int rc = lds_opt_in(opt3, (const void *)k_cond_bwd3<C, T>, 160 * 1024 - 256)) return rc;
-        hipLaunchKernelGGL((k_cond_bwd1<C, T>), dim3(tiles), dim3(64 * JC), ldsc, st, dh, h, a2, wt, g3t, p3t, g2t, part, s, NPXp, logscale);
-        hipLaunchKernelGGL((k_cond_bwd2<C, T>), dim3(tiles), dim3(64 * J), lds2, st, x, (const T *)g2t, wt, w2, a1t, g1t, p1t, s, J, NPXp);
-        hipLaunchKernelGGL((k_cond_bwd3<C, T>), dim3(tiles), dim3(64 * J), lds3, st, (const T *)g1t, wt, dx, s, J, NPXp);
+        if (int rc = lds_opt_in(opt3, (const void *)k_cond_bwd3u<C, T>, 160 * 1024 - 256)) return rc;
+        hipLaunchKernelGGL((k_cond_bwd1<C, T>), dim3(tiles), dim3(64 * JC), ldsc, st, dh, h, a2, wt, g3t, p3t, g2t, tpart, s, P, logscale);
+        hipLaunchKernelGGL((k_cond_bwd2<C, T>), dim3(tiles), dim3(64 * J), lds2, st, x, (const T *)g2t, wt, w2, a1t, g1t, p1t, s, J, P);
+        hipLaunchKernelGGL((k_cond_bwd3u<C, T>), dim3(tiles), dim3(512), lds3, st, (const T *)g1t, wt, u, s.Wd, P);
+        hipLaunchKernelGGL(k_cond_bwd3g<C>, dim3(tiles), dim3(256), 0, st, (const float *)u, dx, s, P);
+        // the three weight gradients
+        WJobs jobs;
+        const int nt1 = (K1 + 15) / 16, nt2 = s.Wd / 16, nt3 = (9 * C + 15) / 16, mt1 = s.Wd / 16, mt23 = (C + 15) / 16;
+        jobs.j[0] = WJob{g1t, p1t, s.Wd, K1, nt1, 0, 0};
+        jobs.j[1] = WJob{g2t, a1t, C, s.Wd, nt2, mt1 * nt1, (size_t)s.Wd * K1};
+        jobs.j[2] = WJob{g3t, p3t, C, 9 * C, nt3, mt1 * nt1 + mt23 * nt2, (size_t)s.Wd * K1 + (size_t)C * s.Wd};
+        const int ntiles = mt1 * nt1 + mt23 * nt2 + mt23 * nt3, S = (P + WSL - 1) / WSL;
+        hipLaunchKernelGGL(k_cond_wgrad<T>, dim3(ntiles * S), dim3(64), 0, st, jobs, gpart, P, S, w.per_slice);
+        hipLaunchKernelGGL(k_cond_wreduce, dim3((unsigned)((w.per_slice + 2 * C + 255) / 256)), dim3(256), 0, st, (const float *)gpart,
+                           (const float *)tpart, grads, w.per_slice, S, tiles, 2 * C);
         IFL_HIP(hipGetLastError());
         return IFL_OK;
     }
@@ -704,24 +900,30 @@ int ifl_cond_forward_f32(const float *x, int x_channels, const float *wt, const 
     IFL_COND_DISPATCH(C, forward(x, wt, b3, a2, h, s, (hipStream_t)stream));
 }
 
+size_t ifl_cond_backward_workspace_bytes(int B, int C, int H, int W, int width, int operands_f32)
+{
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || width <= 0) return 0;
+    return cond_ws(C, width, ifl_cond_pixels_padded(B, H, W), operands_f32 ? sizeof(float) : sizeof(bf16_t)).total;
+}
+
+size_t ifl_cond_grads_floats(int C, int width) { return (size_t)width * 9 * (C / 2) + (size_t)C * width + (size_t)9 * C * C + 2 * (size_t)C; }
+
 int ifl_cond_backward_f32(const float *x, int x_channels, const float *dh, const float *h, const float *a2, const float *wt,
-                          const float *w2, void *g3t, void *p3t, void *g2t, void *a1t, void *g1t, void *p1t, int operands_f32,
-                          float *part, float *dx, int B, int C, int H, int W, int width, float logscale_factor,
-                          ifl_stream_t stream)
+                          const float *w2, int operands_f32, void *ws, size_t ws_bytes, float *grads, float *dx, int B, int C, int H,
+                          int W, int width, float logscale_factor, ifl_stream_t stream)
 {
     clear_error();
     if (int rc = cond_check("ifl_cond_backward_f32", B, C, H, W, width, x_channels)) return rc;
     if (B == 0) return IFL_OK;
-    if (!x || !dh || !h || !a2 || !wt || !w2 || !g3t || !p3t || !g2t || !a1t || !g1t || !p1t || !part || !dx)
-        IFL_FAIL(IFL_EINVAL, "ifl_cond_backward_f32: null pointer");
+    if (!x || !dh || !h || !a2 || !wt || !w2 || !ws || !grads || !dx) IFL_FAIL(IFL_EINVAL, "ifl_cond_backward_f32: null pointer");
+    const size_t need = ifl_cond_backward_workspace_bytes(B, C, H, W, width, operands_f32);
+    if (ws_bytes < need || ((uintptr_t)ws & 255)) IFL_FAIL(IFL_EWORKSPACE, "ifl_cond_backward_f32: %zu bytes of 256-aligned workspace needed", need);
     const CondShape s{B, H, W, width, x_channels};
     hipStream_t st = (hipStream_t)stream;
     if (operands_f32) {
-        IFL_COND_DISPATCH(C, backward(x, dh, h, a2, wt, w2, (float *)g3t, (float *)p3t, (float *)g2t, (float *)a1t, (float *)g1t,
-                                      (float *)p1t, part, dx, s, logscale_factor, st));
+        IFL_COND_DISPATCH(C, template backward<float>(x, dh, h, a2, wt, w2, ws, grads, dx, s, logscale_factor, st));
     }
-    IFL_COND_DISPATCH(C, backward(x, dh, h, a2, wt, w2, (bf16_t *)g3t, (bf16_t *)p3t, (bf16_t *)g2t, (bf16_t *)a1t, (bf16_t *)g1t,
-                                  (bf16_t *)p1t, part, dx, s, logscale_factor, st));
+    IFL_COND_DISPATCH(C, template backward<bf16_t>(x, dh, h, a2, wt, w2, ws, grads, dx, s, logscale_factor, st));
 }
 
 } // extern "C"

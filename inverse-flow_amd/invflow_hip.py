@@ -64,8 +64,9 @@ SIGNATURES = {
     "ifl_cond_pixels_padded": (_i, [_i, _i, _i]),
     "ifl_cond_prep_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "ifl_cond_forward_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "ifl_cond_backward_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i,
-                                   _f, _vp]),
+    "ifl_cond_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "ifl_cond_grads_floats": (_sz, [_i, _i]),
+    "ifl_cond_backward_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "ifl_coupling_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ifl_coupling_backward_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ifl_activation_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -641,9 +642,8 @@ def cond_forward(x, wt, b3, C, width):
 
 
 def cond_backward(x, dh, h, a2, wt, w2, dx, width, logscale_factor, low_precision=False):
-    """dx[:, :C/2] += the input gradient (in place); returns (dW1, dW2, dW3, d logs, d b3) -- the three kernels' gradients
-    through library GEMMs on the operand matrices the kernels write (include/invflow.h): bf16 matrices when low_precision
-    (the bf16 autocast step), fp32 otherwise."""
+    """dx[:, :C/2] += the input gradient (in place); returns (dW1, dW2, dW3, d logs, d b3) (views of one buffer).
+    low_precision (the bf16 autocast step): the operand matrices of the three weight-gradient products are bf16."""
     B, Cx, H, W = _chk4(x, "input")
     C = h.shape[1]
     for t, n in ((dh, "grad_h"), (h, "h"), (a2, "a2"), (wt, "weights"), (w2, "w2"), (dx, "grad_input")):
@@ -651,23 +651,17 @@ def cond_backward(x, dh, h, a2, wt, w2, dx, width, logscale_factor, low_precisio
     if dh.shape != h.shape or a2.shape != h.shape or dx.shape != x.shape:
         raise RuntimeError("conditioner backward: shapes do not match the forward's")
     dev = _same_device(x, dh, h, a2, wt, w2, dx)
-    P = lib().ifl_cond_pixels_padded(B, H, W)
-    K1 = 9 * (C // 2)
-    bf = torch.bfloat16 if low_precision else torch.float32
-    ops = torch.empty((2 * C + 9 * C + 2 * width + K1) * P, dtype=bf, device=dev)  # one allocation, six matrices
-    g3t, p3t, g2t, a1t, g1t, p1t = (m.view(-1, P) for m in ops.split([C * P, 9 * C * P, C * P, width * P, width * P, K1 * P]))
-    part = torch.empty(P // 64, 2 * C, dtype=torch.float32, device=dev)
+    f32 = 0 if low_precision else 1
+    nb = lib().ifl_cond_backward_workspace_bytes(B, C, H, W, width, f32)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)  # (fresh: lives until the kernels of this call have run)
+    grads = torch.empty(lib().ifl_cond_grads_floats(C, width), dtype=torch.float32, device=dev)
     with _on(dev):
-        rc = lib().ifl_cond_backward_f32(_ptr(x), Cx, _ptr(dh), _ptr(h), _ptr(a2), _ptr(wt), _ptr(w2), _ptr(g3t), _ptr(p3t), _ptr(g2t),
-                                         _ptr(a1t), _ptr(g1t), _ptr(p1t), 0 if low_precision else 1, _ptr(part), _ptr(dx), B, C, H, W, width,
-                                         float(logscale_factor), _stream())
+        rc = lib().ifl_cond_backward_f32(_ptr(x), Cx, _ptr(dh), _ptr(h), _ptr(a2), _ptr(wt), _ptr(w2), f32, _ptr(ws), nb, _ptr(grads),
+                                         _ptr(dx), B, C, H, W, width, float(logscale_factor), _stream())
     _check(rc, "ifl_cond_backward_f32")
-    kw = {"out_dtype": torch.float32} if low_precision else {}
-    dw1 = torch.mm(g1t, p1t.t(), **kw).view(width, C // 2, 3, 3)
-    dw2 = torch.mm(g2t, a1t.t(), **kw).view(C, width, 1, 1)
-    dw3 = torch.mm(g3t, p3t.t(), **kw).view(C, C, 3, 3)
-    sums = part.sum(0)
-    return dw1, dw2, dw3, sums[:C], sums[C:]
+    K1 = 9 * (C // 2)
+    dw1, dw2, dw3, dlogs, db3 = grads.split([width * K1, C * width, 9 * C * C, C, C])
+    return dw1.view(width, C // 2, 3, 3), dw2.view(C, width, 1, 1), dw3.view(C, C, 3, 3), dlogs, db3
 
 
 # ---- activations of the Glow step (csrc/glow_step.hip) --------------------------------------------------------------

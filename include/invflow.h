@@ -263,7 +263,7 @@ int ifl_coupling_backward_bf16(const uint16_t *gy, const float *g_logdet, const 
  *
  * ifl_cond_prep_f32: once per weight update -- transposed copies of the kernels and the gain, ifl_cond_weights_floats(C,
  * width) floats (w1 [width][C/2][3][3], w2 [C][width], w3 [C][C][3][3], logs [C]).
- * ifl_cond_forward_f32: a2 [B][C][H][W] (the second ReLU's output, kept for the backward) and h [B][C][H][W].
+ * ifl_cond_forward_f32 (wt from ifl_cond_prep_f32 plus the kernels w1, w2 as they are): a2 [B][C][H][W] (the second ReLU's output, kept for the backward) and h [B][C][H][W].
  * ifl_cond_backward_f32 (dh = gradient of h):
  *   dx[:, :C/2] += the input gradient (dx: [B][x_channels][H][W], already holding the coupling's direct part);
  *   grads [ifl_cond_grads_floats(C, width)] = dW1 [width][C/2][3][3] | dW2 [C][width] | dW3 [C][C][3][3] | d logs [C] | d b3 [C];
@@ -276,12 +276,12 @@ size_t ifl_cond_weights_floats(int C, int width);
 int ifl_cond_pixels_padded(int B, int H, int W);
 int ifl_cond_prep_f32(const float *w1, const float *w2, const float *w3, const float *logs, float *wt, int C, int width,
                       float logscale_factor, ifl_stream_t stream);
-int ifl_cond_forward_f32(const float *x, int x_channels, const float *wt, const float *b3, float *a2, float *h, int B, int C, int H,
-                         int W, int width, ifl_stream_t stream);
+int ifl_cond_forward_f32(const float *x, int x_channels, const float *wt, const float *w1, const float *w2, const float *b3, float *a2,
+                         float *h, int B, int C, int H, int W, int width, ifl_stream_t stream);
 size_t ifl_cond_backward_workspace_bytes(int B, int C, int H, int W, int width, int operands_f32);
 size_t ifl_cond_grads_floats(int C, int width);
 int ifl_cond_backward_f32(const float *x, int x_channels, const float *dh, const float *h, const float *a2, const float *wt,
-                          const float *w2, int operands_f32, void *ws, size_t ws_bytes, float *grads, float *dx, int B, int C, int H,
+                          const float *w1, const float *w2, int operands_f32, void *ws, size_t ws_bytes, float *grads, float *dx, int B, int C, int H,
                           int W, int width, float logscale_factor, ifl_stream_t stream);
 
 /* ---- activations of the Glow step (inf/layers/activations.py) ----------------------------------------------------- */

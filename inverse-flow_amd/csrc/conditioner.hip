@@ -35,6 +35,9 @@ namespace ifl {
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 static constexpr int HC = 16;      // hidden units per register chunk
+#ifndef IFL_COND_MFMA_HIDDEN
+#define IFL_COND_MFMA_HIDDEN 1 // the hidden layer on the matrix cores (k_cond_fwd1m / k_cond_bwd2m); 0: the FMA forms
+#endif
 static constexpr int STAGE = 1024; // floats of a wave's weight stage (256 quads: four per lane)
 
 struct CondShape {
@@ -509,6 +512,201 @@ __global__ __launch_bounds__(512) void k_cond_bwd2(const float *__restrict__ x, 
     }
 }
 
+// ---- the hidden layer on the matrix cores (forward 1 and backward 2, second form) ----------------------------------------------
+// a1[hid][px] = sum_k W1[hid][k] patch[k][px] is a [width x 9C/2] x [9C/2 x 64] product per workgroup: with broadcast weights
+// from LDS the FMA form moves 17 LDS words per 16 FMAs of a lane and is LDS-bound (forward 1 at 18-56 us); as fragments of
+// v_mfma_f32_16x16x4_f32 (exact fp32) it moves 5 words per 1024 MACs.  The workgroup walks the hidden units in chunks of
+// 128 -- one 16-unit tile per wave -- and the k index in chunks of 32: W1 rows [128][32] staged in LDS (the next chunk's
+// loads in flight), the patch [k][64] staged once.  The second product takes the wave's own 16 x 64 tile of relu(a1) -- out
+// through a wave-private LDS tile, back as the right-hand fragment -- against W2's 16 columns.
+template <int C> struct HCfg {
+    static constexpr int CIN = C / 2, K1 = 9 * CIN, K1P = (K1 + 3) / 4 * 4, KC = 32, NKC = (K1P + KC - 1) / KC;
+    static constexpr int PST = 64 + 16, AST = KC + 1, HCH = 128;            // LDS row strides; hidden units per chunk
+    static constexpr int P_FL = NKC * KC * PST, A_FL = HCH * AST, T_FL = 8 * 16 * PST; // patch (k padded to whole chunks), W1 chunk, tiles
+    static constexpr int CP = (C + 15) / 16 * 16, MT2 = CP / 16;
+};
+
+// stage the 3x3 neighbourhoods of the tile as patch[k][PST] (k padded with zero rows)
+template <int C>
+__device__ __forceinline__ void stage_patch_m(float *Ps, const float *__restrict__ x, const Pix &q, const CondShape &s, int lane, int wv)
+{
+    using Hc = HCfg<C>;
+    const int HW = s.H * s.W;
+#pragma unroll 4
+    for (int k = wv; k < Hc::NKC * Hc::KC; k += 8) {
+        const int kk = k < Hc::K1 ? k : 0, ci = kk / 9, tap = kk - ci * 9, dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int yy = q.y + dy, xx = q.x + dx;
+        const bool in = k < Hc::K1 && q.live && yy >= 0 && yy < s.H && xx >= 0 && xx < s.W;
+        const int yc = min(max(yy, 0), s.H - 1), xc = min(max(xx, 0), s.W - 1);
+        const float v = x[((size_t)q.b * s.Cx + ci) * HW + yc * s.W + xc];
+        Ps[k * Hc::PST + lane] = in ? v : 0.f;
+    }
+}
+
+// one chunk of 128 hidden units: acc[n] (n: four 16-pixel column tiles) of this wave's 16-unit tile.  w1: [Wd][K1].
+template <int C>
+__device__ __forceinline__ void hidden_tile_mfma(f4 (&acc)[4], const float *__restrict__ w1, const float *Ps, float *As, int h0, int Wd,
+                                                 int tid, int lane, int wv)
+{
+    using Hc = HCfg<C>;
+    constexpr int NA = Hc::HCH * Hc::KC / 512; // 8 elements per thread and chunk
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = f4{0.f, 0.f, 0.f, 0.f};
+    float ra[NA];
+    auto load = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = tid + 512 * i, hid = e / Hc::KC, k = kc + e % Hc::KC;
+            const int hc = min(h0 + hid, Wd - 1), kcl = min(k, Hc::K1 - 1);
+            const float v = w1[(size_t)hc * Hc::K1 + kcl];
+            ra[i] = (h0 + hid < Wd && k < Hc::K1) ? v : 0.f;
+        }
+    };
+    load(0);
+#pragma unroll 1
+    for (int c = 0; c < Hc::NKC; ++c) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = tid + 512 * i;
+            As[(e / Hc::KC) * Hc::AST + e % Hc::KC] = ra[i];
+        }
+        __syncthreads();
+        if (c + 1 < Hc::NKC) load((c + 1) * Hc::KC);
+        const int ksteps = min(Hc::KC, Hc::K1P - c * Hc::KC) / 4;
+        for (int st = 0; st < ksteps; ++st) {
+            const int kk = 4 * st + (lane >> 4);
+            const float af = As[(16 * wv + (lane & 15)) * Hc::AST + kk];
+            const float *pr = Ps + (size_t)(c * Hc::KC + kk) * Hc::PST + (lane & 15);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, pr[16 * n], acc[n], 0, 0, 0);
+        }
+    }
+}
+
+// ---- forward 1 (matrix cores): a2 = relu(W2 relu(W1 * x1)) ------------------------------------------------------------------
+// LDS: patch | W1 chunk | eight 16 x 64 tiles; the slots [8][CP][64] of the final sum reuse it from the start.
+template <int C>
+__global__ __launch_bounds__(512) void k_cond_fwd1m(const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ w2,
+                                                    float *__restrict__ a2, CondShape s)
+{
+    using Hc = HCfg<C>;
+    extern __shared__ float lds[];
+    float *Ps = lds, *As = lds + Hc::P_FL, *Ts = As + Hc::A_FL;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *mine = Ts + wv * 16 * Hc::PST;
+    const int HW = s.H * s.W, NPX = s.B * HW;
+    const Pix q = pix_of(blockIdx.x * 64 + lane, HW, s.W, NPX);
+    stage_patch_m<C>(Ps, x, q, s, lane, wv);
+    f4 acc2[Hc::MT2][4];
+#pragma unroll
+    for (int m = 0; m < Hc::MT2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc2[m][n] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int h0 = 0; h0 < s.Wd; h0 += Hc::HCH) {
+        const int hb = h0 + 16 * wv; // this wave's 16 hidden units (past Wd: zero weights)
+        // W2 fragments of this tile: A[m = c][kk = hidden]  (w2: [C][Wd])
+        float w2f[Hc::MT2][4];
+#pragma unroll
+        for (int m = 0; m < Hc::MT2; ++m)
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int c = 16 * m + (lane & 15), hh = hb + 4 * st + (lane >> 4);
+                const float v = w2[(size_t)min(c, C - 1) * s.Wd + min(hh, s.Wd - 1)];
+                w2f[m][st] = (c < C && hh < s.Wd) ? v : 0.f;
+            }
+        f4 acc[4];
+        hidden_tile_mfma<C>(acc, w1, Ps, As, h0, s.Wd, tid, lane, wv);
+        // relu(a1) tile -> LDS [hidden 16][PST] -> right-hand fragments
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine[(4 * (lane >> 4) + r) * Hc::PST + 16 * n + (lane & 15)] = fmaxf(acc[n][r], 0.f);
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const float *br = mine + (4 * st + (lane >> 4)) * Hc::PST + (lane & 15);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const float bf = br[16 * n];
+#pragma unroll
+                for (int m = 0; m < Hc::MT2; ++m) acc2[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2f[m][st], bf, acc2[m][n], 0, 0, 0);
+            }
+        }
+    }
+    // sum over the eight waves (slots, wave order), ReLU, store
+    __syncthreads();
+    f4 *slot = (f4 *)lds; // [wave][m][n][lane]
+#pragma unroll
+    for (int m = 0; m < Hc::MT2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) slot[((wv * Hc::MT2 + m) * 4 + n) * 64 + lane] = acc2[m][n];
+    __syncthreads();
+    for (int t = wv; t < Hc::MT2 * 4; t += 8) { // (m, n) tiles over the waves
+        const int m = t / 4, n = t % 4;
+        f4 v = slot[((0 * Hc::MT2 + m) * 4 + n) * 64 + lane];
+        for (int g = 1; g < 8; ++g) v += slot[((g * Hc::MT2 + m) * 4 + n) * 64 + lane];
+        const Pix qq = pix_of(blockIdx.x * 64 + 16 * n + (lane & 15), HW, s.W, NPX);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * m + 4 * (lane >> 4) + r;
+            if (qq.live && c < C) a2[((size_t)qq.b * C + c) * HW + qq.r] = fmaxf(v[r], 0.f);
+        }
+    }
+}
+
+// ---- backward 2 (matrix cores) ------------------------------------------------------------------------------------------------
+// a1 recomputed as above; ga[hid][px] = sum_c W2[c][hid] g2[c][px] the same way (left fragments from W2t [Wd][C], right
+// fragments from g2 staged [c][PST]); g1 = [a1 > 0] ga.  a1t, g1t rows leave in 16-pixel segments; p1t from the staged patch.
+template <int C, class T>
+__global__ __launch_bounds__(512) void k_cond_bwd2m(const float *__restrict__ x, const T *__restrict__ g2t, const float *__restrict__ w1,
+                                                    const float *__restrict__ w2t, T *__restrict__ a1t, T *__restrict__ g1t,
+                                                    T *__restrict__ p1t, CondShape s, int NPXp)
+{
+    using Hc = HCfg<C>;
+    constexpr int CP4 = (C + 3) / 4 * 4;
+    extern __shared__ float lds[];
+    float *Ps = lds, *As = lds + Hc::P_FL, *Gs = As + Hc::A_FL; // Gs: g2 [CP4][PST]
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HW = s.H * s.W, NPX = s.B * HW, p0 = blockIdx.x * 64;
+    const Pix q = pix_of(p0 + lane, HW, s.W, NPX);
+    stage_patch_m<C>(Ps, x, q, s, lane, wv);
+    for (int c = wv; c < CP4; c += 8) Gs[c * Hc::PST + lane] = c < C ? widen(g2t[(size_t)c * NPXp + p0 + lane]) : 0.f;
+    __syncthreads();
+    for (int k = wv; k < Hc::K1; k += 8) put_op(p1t + (size_t)k * NPXp + p0 + lane, Ps[k * Hc::PST + lane]);
+    for (int h0 = 0; h0 < s.Wd; h0 += Hc::HCH) {
+        const int hb = h0 + 16 * wv;
+        float w2f[CP4 / 4]; // A[m = hidden][kk = c] = W2t[hidden][c]
+#pragma unroll
+        for (int st = 0; st < CP4 / 4; ++st) {
+            const int hh = hb + (lane & 15), c = 4 * st + (lane >> 4);
+            const float v = w2t[(size_t)min(hh, s.Wd - 1) * C + min(c, C - 1)];
+            w2f[st] = (hh < s.Wd && c < C) ? v : 0.f;
+        }
+        f4 acc[4], ga[4];
+        hidden_tile_mfma<C>(acc, w1, Ps, As, h0, s.Wd, tid, lane, wv);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) ga[n] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < CP4 / 4; ++st) {
+            const float *br = Gs + (4 * st + (lane >> 4)) * Hc::PST + (lane & 15);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) ga[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2f[st], br[16 * n], ga[n], 0, 0, 0);
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int hh = hb + 4 * (lane >> 4) + r;
+                if (hh < s.Wd) {
+                    const size_t o = (size_t)hh * NPXp + p0 + 16 * n + (lane & 15);
+                    put_op(a1t + o, fmaxf(acc[n][r], 0.f));
+                    put_op(g1t + o, acc[n][r] > 0.f ? ga[n][r] : 0.f);
+                }
+            }
+    }
+}
+
 // ---- backward 3: dx[:, :C/2] += W1^T * g1 (3x3, transposed) ------------------------------------------------------------------
 // Two steps.  (a) u[k][p] = sum_w W1[w][k] g1[w][p], k = ci*9 + tap: what pixel p sends to its neighbour at `tap` -- a
 // [9C/2 x width] x [width x pixels] product on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, the vector FMA
@@ -521,7 +719,9 @@ template <int C> struct UCfg {
     static constexpr int K1 = 9 * (C / 2), MT = (K1 + 15) / 16, K1P = MT * 16;
     static constexpr int MS = MT >= 8 ? 8 : (MT >= 4 ? 4 : (MT >= 2 ? 2 : 1)), KS = 8 / MS; // waves = MS x KS
     static constexpr int MW = (MT + MS - 1) / MS;                                          // k tiles of a wave
-    static constexpr int WCH = 32, AST = WCH + 1, BST = 64 + 16;                           // chunk, padded LDS row strides
+    static constexpr int WCH = K1P <= 32 ? 128 : (K1P <= 64 ? 64 : 32); // hidden units per chunk (few k rows: longer chunks,
+                                                                        // fewer exposed round trips)
+    static constexpr int AST = WCH + 1, BST = 64 + 16;                  // padded LDS row strides
     static constexpr int A_FL = K1P * AST, B_FL = WCH * BST;
     static constexpr int NA = (K1P * WCH + 511) / 512, NBL = WCH * 64 / 512;               // elements per thread and chunk
     static constexpr int SLOT_FL = KS > 1 ? 8 * MW * 4 * 256 : 0, LDS_FL = A_FL + B_FL > SLOT_FL ? A_FL + B_FL : SLOT_FL;
@@ -790,7 +990,8 @@ static CondWs cond_ws(int C, int Wd, int P, size_t elem)
 
 template <int C> struct CondLaunch {
     static constexpr int K1 = 9 * (C / 2);
-    static int forward(const float *x, const float *wt, const float *b3, float *a2, float *h, CondShape s, hipStream_t st)
+    static int forward(const float *x, const float *wt, const float *w1, const float *w2, const float *b3, float *a2, float *h,
+                       CondShape s, hipStream_t st)
     {
         static LdsOptIn opt;
         static LdsOptIn opt2;
@@ -800,13 +1001,23 @@ template <int C> struct CondLaunch {
         constexpr int JC = CSplit<C>::JC, ldsc = (JC * C * 64 + JC * STAGE) * (int)sizeof(float);
         if (int rc = lds_opt_in(opt, (const void *)k_cond_fwd1<C>, 160 * 1024 - 256)) return rc;
         if (int rc = lds_opt_in(opt2, (const void *)k_cond_fwd2<C>, 160 * 1024 - 256)) return rc;
-        hipLaunchKernelGGL(k_cond_fwd1<C>, dim3(tiles), dim3(64 * J), lds, st, x, wt, a2, s, J);
+        if (IFL_COND_MFMA_HIDDEN) {
+            using Hc = HCfg<C>;
+            static LdsOptIn optm;
+            constexpr int a_m = Hc::P_FL + Hc::A_FL + Hc::T_FL, b_m = 8 * Hc::MT2 * 4 * 64 * 4;
+            constexpr int ldsm = (a_m > b_m ? a_m : b_m) * (int)sizeof(float);
+            static_assert(ldsm <= 160 * 1024 - 256, "forward 1 fits the LDS");
+            if (int rc = lds_opt_in(optm, (const void *)k_cond_fwd1m<C>, 160 * 1024 - 256)) return rc;
+            hipLaunchKernelGGL(k_cond_fwd1m<C>, dim3(tiles), dim3(512), ldsm, st, x, w1, w2, a2, s);
+        } else
+            hipLaunchKernelGGL(k_cond_fwd1<C>, dim3(tiles), dim3(64 * J), lds, st, x, wt, a2, s, J);
         hipLaunchKernelGGL(k_cond_fwd2<C>, dim3(tiles), dim3(64 * JC), ldsc, st, (const float *)a2, wt, b3, h, s);
         IFL_HIP(hipGetLastError());
         return IFL_OK;
     }
     template <class T>
-    static int backward(const float *x, const float *dh, const float *h, const float *a2, const float *wt, const float *w2, void *ws,
+    static int backward(const float *x, const float *dh, const float *h, const float *a2, const float *wt, const float *w1,
+                        const float *w2, void *ws,
                         float *grads, float *dx, CondShape s, float logscale, hipStream_t st)
     {
         static LdsOptIn opt1, opt2, opt3;
@@ -823,7 +1034,16 @@ template <int C> struct CondLaunch {
         if (int rc = lds_opt_in(opt2, (const void *)k_cond_bwd2<C, T>, 160 * 1024 - 256)) return rc;
         if (int rc = lds_opt_in(opt3, (const void *)k_cond_bwd3u<C, T>, 160 * 1024 - 256)) return rc;
         hipLaunchKernelGGL((k_cond_bwd1<C, T>), dim3(tiles), dim3(64 * JC), ldsc, st, dh, h, a2, wt, g3t, p3t, g2t, tpart, s, P, logscale);
-        hipLaunchKernelGGL((k_cond_bwd2<C, T>), dim3(tiles), dim3(64 * J), lds2, st, x, (const T *)g2t, wt, w2, a1t, g1t, p1t, s, J, P);
+        if (IFL_COND_MFMA_HIDDEN) {
+            using Hc = HCfg<C>;
+            static LdsOptIn optm;
+            constexpr int ldsm = (Hc::P_FL + Hc::A_FL + (C + 3) / 4 * 4 * Hc::PST) * (int)sizeof(float);
+            static_assert(ldsm <= 160 * 1024 - 256, "backward 2 fits the LDS");
+            if (int rc = lds_opt_in(optm, (const void *)k_cond_bwd2m<C, T>, 160 * 1024 - 256)) return rc;
+            hipLaunchKernelGGL((k_cond_bwd2m<C, T>), dim3(tiles), dim3(512), ldsm, st, x, (const T *)g2t, w1,
+                               wt + (size_t)K1 * s.Wd, a1t, g1t, p1t, s, P);
+        } else
+            hipLaunchKernelGGL((k_cond_bwd2<C, T>), dim3(tiles), dim3(64 * J), lds2, st, x, (const T *)g2t, wt, w2, a1t, g1t, p1t, s, J, P);
         hipLaunchKernelGGL((k_cond_bwd3u<C, T>), dim3(tiles), dim3(512), lds3, st, (const T *)g1t, wt, u, s.Wd, P);
         hipLaunchKernelGGL(k_cond_bwd3g<C>, dim3(tiles), dim3(256), 0, st, (const float *)u, dx, s, P);
         // the three weight gradients
@@ -889,15 +1109,15 @@ int ifl_cond_prep_f32(const float *w1, const float *w2, const float *w3, const f
     return IFL_OK;
 }
 
-int ifl_cond_forward_f32(const float *x, int x_channels, const float *wt, const float *b3, float *a2, float *h, int B, int C, int H,
-                         int W, int width, ifl_stream_t stream)
+int ifl_cond_forward_f32(const float *x, int x_channels, const float *wt, const float *w1, const float *w2, const float *b3, float *a2,
+                         float *h, int B, int C, int H, int W, int width, ifl_stream_t stream)
 {
     clear_error();
     if (int rc = cond_check("ifl_cond_forward_f32", B, C, H, W, width, x_channels)) return rc;
     if (B == 0) return IFL_OK;
-    if (!x || !wt || !a2 || !h) IFL_FAIL(IFL_EINVAL, "ifl_cond_forward_f32: null pointer");
+    if (!x || !wt || !w1 || !w2 || !a2 || !h) IFL_FAIL(IFL_EINVAL, "ifl_cond_forward_f32: null pointer");
     const CondShape s{B, H, W, width, x_channels};
-    IFL_COND_DISPATCH(C, forward(x, wt, b3, a2, h, s, (hipStream_t)stream));
+    IFL_COND_DISPATCH(C, forward(x, wt, w1, w2, b3, a2, h, s, (hipStream_t)stream));
 }
 
 size_t ifl_cond_backward_workspace_bytes(int B, int C, int H, int W, int width, int operands_f32)
@@ -909,21 +1129,21 @@ size_t ifl_cond_backward_workspace_bytes(int B, int C, int H, int W, int width, 
 size_t ifl_cond_grads_floats(int C, int width) { return (size_t)width * 9 * (C / 2) + (size_t)C * width + (size_t)9 * C * C + 2 * (size_t)C; }
 
 int ifl_cond_backward_f32(const float *x, int x_channels, const float *dh, const float *h, const float *a2, const float *wt,
-                          const float *w2, int operands_f32, void *ws, size_t ws_bytes, float *grads, float *dx, int B, int C, int H,
+                          const float *w1, const float *w2, int operands_f32, void *ws, size_t ws_bytes, float *grads, float *dx, int B, int C, int H,
                           int W, int width, float logscale_factor, ifl_stream_t stream)
 {
     clear_error();
     if (int rc = cond_check("ifl_cond_backward_f32", B, C, H, W, width, x_channels)) return rc;
     if (B == 0) return IFL_OK;
-    if (!x || !dh || !h || !a2 || !wt || !w2 || !ws || !grads || !dx) IFL_FAIL(IFL_EINVAL, "ifl_cond_backward_f32: null pointer");
+    if (!x || !dh || !h || !a2 || !wt || !w1 || !w2 || !ws || !grads || !dx) IFL_FAIL(IFL_EINVAL, "ifl_cond_backward_f32: null pointer");
     const size_t need = ifl_cond_backward_workspace_bytes(B, C, H, W, width, operands_f32);
     if (ws_bytes < need || ((uintptr_t)ws & 255)) IFL_FAIL(IFL_EWORKSPACE, "ifl_cond_backward_f32: %zu bytes of 256-aligned workspace needed", need);
     const CondShape s{B, H, W, width, x_channels};
     hipStream_t st = (hipStream_t)stream;
     if (operands_f32) {
-        IFL_COND_DISPATCH(C, template backward<float>(x, dh, h, a2, wt, w2, ws, grads, dx, s, logscale_factor, st));
+        IFL_COND_DISPATCH(C, template backward<float>(x, dh, h, a2, wt, w1, w2, ws, grads, dx, s, logscale_factor, st));
     }
-    IFL_COND_DISPATCH(C, template backward<bf16_t>(x, dh, h, a2, wt, w2, ws, grads, dx, s, logscale_factor, st));
+    IFL_COND_DISPATCH(C, template backward<bf16_t>(x, dh, h, a2, wt, w1, w2, ws, grads, dx, s, logscale_factor, st));
 }
 
 } // extern "C"

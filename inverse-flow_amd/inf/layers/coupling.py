@@ -75,18 +75,19 @@ class _CondAffine(torch.autograd.Function):
     @_fwd32
     def forward(ctx, x, w1, w2, w3, b3, logs, logscale, lowp):
         x = x.contiguous()
-        wt = H.cond_prep(w1.contiguous(), w2.contiguous(), w3.contiguous(), logs.contiguous(), logscale)
-        a2, h = H.cond_forward(x, wt, b3, w3.shape[0], w1.shape[0])
-        ctx.save_for_backward(x, h, a2, wt, w2)
+        w1, w2 = w1.contiguous(), w2.contiguous()
+        wt = H.cond_prep(w1, w2, w3.contiguous(), logs.contiguous(), logscale)
+        a2, h = H.cond_forward(x, wt, w1, w2, b3, w3.shape[0], w1.shape[0])
+        ctx.save_for_backward(x, h, a2, wt, w1, w2)
         ctx.logscale, ctx.has_bias, ctx.lowp = logscale, b3 is not None, lowp
         return H.coupling(x, h)
 
     @staticmethod
     @_bwd32
     def backward(ctx, gy, gld):
-        x, h, a2, wt, w2 = ctx.saved_tensors
+        x, h, a2, wt, w1, w2 = ctx.saved_tensors
         gx, gh = H.coupling_backward(gy.contiguous(), gld.contiguous() if gld is not None else None, x, h)
-        dw1, dw2, dw3, dlogs, db3 = H.cond_backward(x, gh, h, a2, wt, w2.contiguous(), gx, w2.shape[1], ctx.logscale, ctx.lowp)
+        dw1, dw2, dw3, dlogs, db3 = H.cond_backward(x, gh, h, a2, wt, w1, w2, gx, w2.shape[1], ctx.logscale, ctx.lowp)
         return gx, dw1, dw2, dw3, (db3 if ctx.has_bias else None), dlogs, None, None
 
 
@@ -118,9 +119,9 @@ class Coupling(FlowLayer):
 
     def _fused_h(self, x):
         c1, c2, c3 = self.net[0], self.net[2], self.net[4]
-        wt = H.cond_prep(c1.weight.detach().contiguous(), c2.weight.detach().contiguous(), c3.weight.detach().contiguous(),
-                         c3.logs.detach().contiguous(), c3.logscale_factor)
-        return H.cond_forward(x, wt, None if c3.bias is None else c3.bias.detach(), self.n_channels, self.width)[1]
+        w1, w2 = c1.weight.detach().contiguous(), c2.weight.detach().contiguous()
+        wt = H.cond_prep(w1, w2, c3.weight.detach().contiguous(), c3.logs.detach().contiguous(), c3.logscale_factor)
+        return H.cond_forward(x, wt, w1, w2, None if c3.bias is None else c3.bias.detach(), self.n_channels, self.width)[1]
 
     def _conditioner(self, x, context):
         assert (context is not None) == self.uses_context

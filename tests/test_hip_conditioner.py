@@ -100,4 +100,5 @@ def test_unsupported_shapes_keep_the_convolutions_and_bad_calls_fail_loudly():
     y, ld = layer(x)  # zero-initialised last convolution: the identity
     assert torch.allclose(y.detach(), x) and float(ld.detach().abs().max()) == 0.0
     with pytest.raises(RuntimeError, match="not one of"):
-        Hh.cond_forward(x, torch.zeros(8, device="cuda"), None, 6, 64)
+        z = torch.zeros(8, device="cuda")
+        Hh.cond_forward(x, z, z, z, None, 6, 64)

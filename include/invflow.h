@@ -281,7 +281,7 @@ int ifl_cond_forward_f32(const float *x, int x_channels, const float *wt, const 
 size_t ifl_cond_backward_workspace_bytes(int B, int C, int H, int W, int width, int operands_f32);
 size_t ifl_cond_grads_floats(int C, int width);
 int ifl_cond_backward_f32(const float *x, int x_channels, const float *dh, const float *h, const float *a2, const float *wt,
-                          const float *w1, const float *w2, int operands_f32, void *ws, size_t ws_bytes, float *grads, float *dx, int B, int C, int H,
+                          const float *w1, int operands_f32, void *ws, size_t ws_bytes, float *grads, float *dx, int B, int C, int H,
                           int W, int width, float logscale_factor, ifl_stream_t stream);
 
 /* ---- activations of the Glow step (inf/layers/activations.py) ----------------------------------------------------- */

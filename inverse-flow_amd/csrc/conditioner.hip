@@ -7,26 +7,28 @@
 // backward (layout and precision casts, convolutions, their zero-fills and reductions, ReLUs, the gain) at ~4.5 us each
 // in a graph replay: two thirds of the whole step (tools/time_stub_conditioner.py).  Here:
 //
-//   forward   k_cond_fwd1   a2 = relu(W2 relu(W1 * x1))     one pass; the `width`-channel hidden activation never leaves
-//                                                            registers (16 hidden units at a time)
+//   forward   k_cond_fwd1m  a2 = relu(W2 relu(W1 * x1))     both products on the fp32 matrix cores; the `width`-channel hidden
+//                                                            activation goes from accumulators through an LDS tile
+//                                                            into the second product and never leaves the CU
 //             k_cond_fwd2   h  = (W3 * a2 + b3) exp(3 logs)
-//   backward  k_cond_bwd1   g3 = dh gain, d logs, d b3, g2 = relu'(a2) (W3^T * g3), and the two operand matrices of dW3
-//             k_cond_bwd2   hidden activation recomputed, g1 = relu'(a1) W2^T g2, and the operand matrices of dW1, dW2
-//             k_cond_bwd3u  u = W1^T g1 per pixel and tap, on the fp32 matrix cores;  k_cond_bwd3g  dx1 += the nine taps of u
-//             k_cond_wgrad  the three weight gradients: [rows x pixels] x [pixels x cols] products with a long reduction and a
-//                           small output, from operand matrices the kernels above write pixel-major; k_cond_wreduce adds its
-//                           slices (and the per-tile sums of d logs, d b3)
+//   backward  k_cond_bwd1   g3 = dh gain, per-tile sums of d logs / d b3, g2 = relu'(a2) (W3^T * g3), operand matrices of dW3
+//             k_cond_bwd2m  hidden activation recomputed, g1 = relu'(a1) W2^T g2 (matrix cores), operand matrices of dW1, dW2
+//             k_cond_bwd3u  u = W1^T g1 per pixel and tap (matrix cores);  k_cond_bwd3g  dx1 += the nine taps of u
+//             k_cond_wgrad  the three weight gradients: [rows x pixels] x [pixels x cols] products with a long reduction and
+//                           a small output, from operand matrices the kernels above write pixel-major (bf16 under autocast,
+//                           fp32 otherwise), a 16x16 tile and 512 pixels per wave;  k_cond_wreduce adds the slices in order
 //
-// Arithmetic: fp32 FMA on the fp32 master weights (nothing is cast per step).  A workgroup owns 64 pixels (a lane = a
-// pixel) and splits the reduction index -- hidden units, or input channels of the 3x3 over C -- over its J <= 8 waves,
-// whose partial sums meet in LDS slots and are added in wave order.  The work is far from any roofline (64-600 workgroups
-// of a few thousand FMAs per lane at one or two waves per SIMD): what decides the time is the number of exposed memory
-// round trips.  So every wave streams ITS weights (read once, 4-14 KB) through a 4 KB LDS stage: a block of up to 256
-// 16-byte quads in one batch of coalesced loads, consumed by uniform-address (broadcast) ds_reads.  [Scalar
-// loads look natural for wave-uniform weights and were tried first: each 64-byte line is a cold miss of the scalar cache
-// and s_waitcnt lgkmcnt(0) exposes every one -- 20-50 us per kernel instead of 3-8.]  Activation neighbourhoods are
-// loaded in one batch before the first FMA.  No float atomics: every sum has one owner and a fixed order (results are
-// reproducible bit for bit).
+// Arithmetic: fp32 on the fp32 master weights (nothing is cast per step): v_mfma_f32_16x16x4_f32 is exact fp32 at the
+// vector FMA rate, but its operands are fragments -- 5 LDS words per 1024 MACs.  [The first forms of these kernels used
+// FMAs with wave-uniform weights: through the scalar cache every 64-byte line of a weight stream read once is an exposed
+// miss (s_waitcnt lgkmcnt(0): scalar loads return out of order); broadcast from LDS, 17 words per 16 FMAs of a lane made
+// them LDS-bound at 20-120 us a kernel.  The two 3x3 convolutions over C channels (forward 2, backward 1) are small enough
+// to stay on that form: the reduction channels split over the eight waves of a workgroup, each wave's weights staged in a
+// 4 KB LDS block, partial sums meeting in LDS slots.]  A workgroup owns 64 pixels.  The work is far from any roofline --
+// what decides the time is the number of exposed memory round trips and launches: neighbourhood loads are unconditional,
+// from clamped coordinates, and issued in one batch (a conditional load is a branch, and a branch per load serialises the
+// round trips); the next chunk of weights is in flight while the current one is multiplied.  No float atomics: every sum
+// has one owner and a fixed order (results are reproducible bit for bit).
 #include "ifl_common.h"
 #include "bf16_util.h"
 
@@ -35,9 +37,6 @@ namespace ifl {
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 static constexpr int HC = 16;      // hidden units per register chunk
-#ifndef IFL_COND_MFMA_HIDDEN
-#define IFL_COND_MFMA_HIDDEN 1 // the hidden layer on the matrix cores (k_cond_fwd1m / k_cond_bwd2m); 0: the FMA forms
-#endif
 static constexpr int STAGE = 1024; // floats of a wave's weight stage (256 quads: four per lane)
 
 struct CondShape {
@@ -76,8 +75,8 @@ __device__ __forceinline__ void blk_copy(float *wl, const Blk &b, int lane)
 
 // ---- weights: transposed copies + the gain ---------------------------------------------------------------------------
 // wt = [ W1t: K1 x Wd | W2t: Wd x C | W3t: 9C x C (k3 = ci*9+tap major, co minor) | W3b: 9C x C ((co*9+tap) major, ci
-//        minor) | gain: C | W1r: Wd x 9 x C/2 (w major, tap, ci minor) ]
-__host__ __device__ inline size_t cond_wt_floats(int C, int Wd) { return (size_t)18 * (C / 2) * Wd + (size_t)Wd * C + (size_t)18 * C * C + C; }
+//        minor) | gain: C ]
+__host__ __device__ inline size_t cond_wt_floats(int C, int Wd) { return (size_t)9 * (C / 2) * Wd + (size_t)Wd * C + (size_t)18 * C * C + C; }
 
 __global__ __launch_bounds__(256) void k_cond_prep(const float *__restrict__ w1, const float *__restrict__ w2,
                                                     const float *__restrict__ w3, const float *__restrict__ logs,
@@ -85,7 +84,7 @@ __global__ __launch_bounds__(256) void k_cond_prep(const float *__restrict__ w1,
 {
     const int K1 = 9 * (C / 2);
     const size_t n1 = (size_t)K1 * Wd, n2 = (size_t)Wd * C, n3 = (size_t)9 * C * C;
-    const size_t total = 2 * n1 + n2 + 2 * n3 + C;
+    const size_t total = n1 + n2 + 2 * n3 + C;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         float v;
         if (i < n1) { // W1t[k][w] = W1[w][k]
@@ -103,12 +102,8 @@ __global__ __launch_bounds__(256) void k_cond_prep(const float *__restrict__ w1,
             const size_t j = i - n1 - n2 - n3;
             const int q = (int)(j / C), ci = (int)(j % C), co = q / 9, tap = q % 9;
             v = w3[((size_t)co * C + ci) * 9 + tap];
-        } else if (i < n1 + n2 + 2 * n3 + C) {
+        } else {
             v = expf(logs[i - n1 - n2 - 2 * n3] * logscale);
-        } else { // W1r[w][tap][ci] = W1[w][ci][tap]
-            const size_t j = i - n1 - n2 - 2 * n3 - C;
-            const int CIN = C / 2, w = (int)(j / K1), q = (int)(j % K1), tap = q / CIN, ci = q % CIN;
-            v = w1[(size_t)w * K1 + ci * 9 + tap];
         }
         wt[i] = v;
     }
@@ -130,61 +125,6 @@ __device__ __forceinline__ Pix pix_of(int p, int HW, int W, int NPX)
     q.y = q.r / W;
     q.x = q.r - q.y * W;
     return q;
-}
-
-// the 3x3 neighbourhood of the head channels of x around every pixel of the tile, tap-major rows of 64: patch[k][lane],
-// k = ci*9 + (dy*3+dx); zero outside the image.  All waves of the workgroup share the work.
-template <int CIN>
-__device__ __forceinline__ void stage_patch(float *patch, const float *__restrict__ x, const Pix &q, const CondShape &s, int lane,
-                                            int wv, int J)
-{
-    const int HW = s.H * s.W;
-    // (loads are unconditional, from clamped coordinates, and zeroed afterwards: a conditional load is a branch and a
-    // branch per load serialises the round trips)
-#pragma unroll 4
-    for (int k = wv; k < 9 * CIN; k += J) {
-        const int ci = k / 9, tap = k - ci * 9, dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        const int yy = q.y + dy, xx = q.x + dx;
-        const bool in = q.live && yy >= 0 && yy < s.H && xx >= 0 && xx < s.W;
-        const int yc = min(max(yy, 0), s.H - 1), xc = min(max(xx, 0), s.W - 1);
-        const float v = x[((size_t)q.b * s.Cx + ci) * HW + yc * s.W + xc];
-        patch[k * 64 + lane] = in ? v : 0.f;
-    }
-}
-
-// The first convolution's weights go through the stage in sub-blocks of KB = 9 CB rows (<= 54) of 16 hidden units.
-template <int CIN> struct W1Split {
-    static constexpr int CB = CIN <= 6 ? CIN : (CIN % 6 == 0 ? 6 : 4), KB = 9 * CB, NS = CIN / CB;
-    static_assert(CIN % CB == 0 && KB * 4 <= 256, "sub-blocks tile the input channels and fit the stage");
-};
-
-// a1[j] += sum_{k in sub-block} wl[k][j] patch[k0 + k]   (reads of row k + 1 ahead of the FMAs of row k; fenced like rows_fma)
-template <int KB> __device__ __forceinline__ void hidden_block(float (&a1)[HC], const float *patch, const float *wl, int k0, int lane)
-{
-    f4 wn[HC / 4];
-    float pn = patch[k0 * 64 + lane];
-#pragma unroll
-    for (int u = 0; u < HC / 4; ++u) wn[u] = ((const f4 *)wl)[u];
-#pragma unroll 2
-    for (int k = 0; k < KB; ++k) {
-        f4 w[HC / 4];
-        const float pv = pn;
-#pragma unroll
-        for (int u = 0; u < HC / 4; ++u) w[u] = wn[u];
-        const int kn = k + 1 < KB ? k + 1 : k; // (the last iteration re-reads its own row)
-        pn = patch[(k0 + kn) * 64 + lane];
-#pragma unroll
-        for (int u = 0; u < HC / 4; ++u) wn[u] = ((const f4 *)(wl + kn * HC))[u];
-#pragma unroll
-        for (int u = 0; u < HC / 4; ++u) {
-            a1[4 * u + 0] = fmaf(w[u][0], pv, a1[4 * u + 0]);
-            a1[4 * u + 1] = fmaf(w[u][1], pv, a1[4 * u + 1]);
-            a1[4 * u + 2] = fmaf(w[u][2], pv, a1[4 * u + 2]);
-            a1[4 * u + 3] = fmaf(w[u][3], pv, a1[4 * u + 3]);
-        }
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    }
 }
 
 // acc[c] += sum_j rows[j][c] v[j]  for a staged block of NJ rows of RL floats (broadcast reads), in segments of up to 16
@@ -217,82 +157,6 @@ template <int RL, int NJ> __device__ __forceinline__ void rows_fma(float (&acc)[
         }
         asm volatile("" ::: "memory"); // (later reads stay below this line)
         __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// the same with v in LDS (vl[j][lane]) and the row loop rolled: for the long blocks (16 x C, C x 16), where the unrolled form
-// costs hundreds of registers whatever the fences say
-template <int RL> __device__ __forceinline__ void rows_fma_lds(float (&acc)[RL], const float *wl, const float *vl, int nj, int lane)
-{
-#pragma unroll 2
-    for (int j = 0; j < nj; ++j) {
-        const float vj = vl[j * 64 + lane];
-        const f4 *wr = (const f4 *)(wl + j * RL);
-#pragma unroll
-        for (int u = 0; u < RL / 4; ++u) {
-            const f4 w = wr[u];
-            acc[4 * u + 0] = fmaf(w[0], vj, acc[4 * u + 0]);
-            acc[4 * u + 1] = fmaf(w[1], vj, acc[4 * u + 1]);
-            acc[4 * u + 2] = fmaf(w[2], vj, acc[4 * u + 2]);
-            acc[4 * u + 3] = fmaf(w[3], vj, acc[4 * u + 3]);
-        }
-    }
-}
-
-// ---- forward 1: a2 = relu(W2 relu(W1 * x1)) ---------------------------------------------------------------------------
-// LDS: patch [K1][64] | stage [J][STAGE] | hidden [J][16][64]; the slots [J][C][64] of the final sum reuse it from the start.
-template <int C>
-__global__ __launch_bounds__(512) void k_cond_fwd1(const float *__restrict__ x, const float *__restrict__ wt, float *__restrict__ a2,
-                                                   CondShape s, int J)
-{
-    constexpr int CIN = C / 2, K1 = 9 * CIN, KB = W1Split<CIN>::KB, NS = W1Split<CIN>::NS;
-    extern __shared__ float lds[];
-    float *patch = lds, *red = lds;
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    float *wl = lds + K1 * 64 + wv * STAGE, *vl = lds + K1 * 64 + J * STAGE + wv * HC * 64;
-    const int HW = s.H * s.W, NPX = s.B * HW;
-    const Pix q = pix_of(blockIdx.x * 64 + lane, HW, s.W, NPX);
-    const float *__restrict__ w1t = wt, *__restrict__ w2t = wt + (size_t)K1 * s.Wd;
-    const int per = s.Wd / J, w0 = wv * per, nblk = (per / HC) * (NS + 1);
-    auto blk = [&](int t) {
-        const int wb = w0 + (t / (NS + 1)) * HC, sb = t % (NS + 1);
-        return sb < NS ? Blk{w1t + (size_t)sb * KB * s.Wd + wb, KB * 4, s.Wd} : Blk{w2t + (size_t)wb * C, 4 * C, 0};
-    };
-    stage_patch<CIN>(patch, x, q, s, lane, wv, J);
-    float acc[C], a1[HC];
-#pragma unroll
-    for (int c = 0; c < C; ++c) acc[c] = 0.f;
-    for (int t = 0; t < nblk; ++t) {
-        __syncthreads();
-        blk_copy(wl, blk(t), lane);
-        __syncthreads();
-        const int sb = t % (NS + 1);
-        if (sb == 0) {
-#pragma unroll
-            for (int j = 0; j < HC; ++j) a1[j] = 0.f;
-        }
-        if (sb < NS) {
-            hidden_block<KB>(a1, patch, wl, sb * KB, lane);
-        } else {
-#pragma unroll
-            for (int j = 0; j < HC; ++j) vl[j * 64 + lane] = fmaxf(a1[j], 0.f); // (a wave reads back its own lanes' values)
-            rows_fma_lds<C>(acc, wl, vl, HC, lane);
-        }
-    }
-    if (J > 1) { // one slot per wave, summed in wave order
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < C; ++c) red[(wv * C + c) * 64 + lane] = acc[c];
-        __syncthreads();
-        if (q.live)
-            for (int c = wv; c < C; c += J) {
-                float t = 0.f;
-                for (int j = 0; j < J; ++j) t += red[(j * C + c) * 64 + lane];
-                a2[((size_t)q.b * C + c) * HW + q.r] = fmaxf(t, 0.f);
-            }
-    } else if (q.live) {
-#pragma unroll
-        for (int c = 0; c < C; ++c) a2[((size_t)q.b * C + c) * HW + q.r] = fmaxf(acc[c], 0.f);
     }
 }
 
@@ -459,60 +323,7 @@ __global__ __launch_bounds__(512) void k_cond_bwd1(const float *__restrict__ dh,
     }
 }
 
-// ---- backward 2 -----------------------------------------------------------------------------------------------------------
-// a1 recomputed; g1 = [a1 > 0] W2^T g2; operand matrices a1t [Wd][NPXp] (after the ReLU), g1t [Wd][NPXp], p1t [K1][NPXp]:
-// dW2 = g2t a1t^T, dW1 = g1t p1t^T.   LDS: patch [K1][64] | stage [J][STAGE] | g2 [C][64]
-template <int C, class T>
-__global__ __launch_bounds__(512) void k_cond_bwd2(const float *__restrict__ x, const T *__restrict__ g2t, const float *__restrict__ wt,
-                                                   const float *__restrict__ w2, T *__restrict__ a1t, T *__restrict__ g1t,
-                                                   T *__restrict__ p1t, CondShape s, int J, int NPXp)
-{
-    constexpr int CIN = C / 2, K1 = 9 * CIN, KB = W1Split<CIN>::KB, NS = W1Split<CIN>::NS;
-    extern __shared__ float lds[];
-    float *patch = lds;
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    float *wl = lds + K1 * 64 + wv * STAGE;
-    const int HW = s.H * s.W, NPX = s.B * HW;
-    const int p = blockIdx.x * 64 + lane;
-    const Pix q = pix_of(p, HW, s.W, NPX);
-    const float *__restrict__ w1t = wt;
-    const int per = s.Wd / J, w0 = wv * per, nblk = (per / HC) * (NS + 1);
-    auto blk = [&](int t) { // NS sub-blocks of W1t, then the chunk's 16 columns of W2 [C][Wd]
-        const int wb = w0 + (t / (NS + 1)) * HC, sb = t % (NS + 1);
-        return sb < NS ? Blk{w1t + (size_t)sb * KB * s.Wd + wb, KB * 4, s.Wd} : Blk{w2 + wb, C * 4, s.Wd};
-    };
-    stage_patch<CIN>(patch, x, q, s, lane, wv, J);
-    float *g2l = lds + K1 * 64 + J * STAGE;
-    for (int c = wv; c < C; c += J) g2l[c * 64 + lane] = widen(g2t[(size_t)c * NPXp + p]);
-    float a1[HC];
-    for (int t = 0; t < nblk; ++t) {
-        __syncthreads();
-        blk_copy(wl, blk(t), lane);
-        __syncthreads();
-        if (t == 0)
-            for (int k = wv; k < K1; k += J) put_op(p1t + (size_t)k * NPXp + p, patch[k * 64 + lane]);
-        const int wb = w0 + (t / (NS + 1)) * HC, sb = t % (NS + 1);
-        if (sb == 0) {
-#pragma unroll
-            for (int j = 0; j < HC; ++j) a1[j] = 0.f;
-        }
-        if (sb < NS) {
-            hidden_block<KB>(a1, patch, wl, sb * KB, lane);
-        } else { // wl = [c][16]: ga[j] = sum_c W2[c][wb + j] g2[c]
-            float ga[HC];
-#pragma unroll
-            for (int j = 0; j < HC; ++j) ga[j] = 0.f;
-            rows_fma_lds<HC>(ga, wl, g2l, C, lane);
-#pragma unroll
-            for (int j = 0; j < HC; ++j) {
-                put_op(a1t + (size_t)(wb + j) * NPXp + p, fmaxf(a1[j], 0.f));
-                put_op(g1t + (size_t)(wb + j) * NPXp + p, a1[j] > 0.f ? ga[j] : 0.f);
-            }
-        }
-    }
-}
-
-// ---- the hidden layer on the matrix cores (forward 1 and backward 2, second form) ----------------------------------------------
+// ---- the hidden layer on the matrix cores (forward 1 and backward 2) -------------------------------------------------------
 // a1[hid][px] = sum_k W1[hid][k] patch[k][px] is a [width x 9C/2] x [9C/2 x 64] product per workgroup: with broadcast weights
 // from LDS the FMA form moves 17 LDS words per 16 FMAs of a lane and is LDS-bound (forward 1 at 18-56 us); as fragments of
 // v_mfma_f32_16x16x4_f32 (exact fp32) it moves 5 words per 1024 MACs.  The workgroup walks the hidden units in chunks of
@@ -962,15 +773,6 @@ __global__ __launch_bounds__(256) void k_cond_wreduce(const float *__restrict__ 
     }
 }
 
-// hidden units are split over J waves: as many as divide them into whole chunks, up to 8 (work per wave is small and latency
-// bound: more waves, shorter chains)
-static int pick_j(int Wd)
-{
-    int J = 1;
-    while (J < 8 && Wd % (2 * J * HC) == 0) J *= 2;
-    return J;
-}
-
 // workspace of the backward (byte offsets, 256-aligned): operand matrices | u | per-tile sums | per-slice partial gradients
 struct CondWs {
     size_t ops, u, tpart, gpart, per_slice, total;
@@ -993,15 +795,11 @@ template <int C> struct CondLaunch {
     static int forward(const float *x, const float *wt, const float *w1, const float *w2, const float *b3, float *a2, float *h,
                        CondShape s, hipStream_t st)
     {
-        static LdsOptIn opt;
         static LdsOptIn opt2;
-        const int NPX = s.B * s.H * s.W, tiles = (NPX + 63) / 64, J = pick_j(s.Wd);
-        const int a_ = K1 * 64 + J * STAGE + J * HC * 64, b_ = J > 1 ? J * C * 64 : 0;
-        const int lds = (a_ > b_ ? a_ : b_) * (int)sizeof(float);
+        const int NPX = s.B * s.H * s.W, tiles = (NPX + 63) / 64;
         constexpr int JC = CSplit<C>::JC, ldsc = (JC * C * 64 + JC * STAGE) * (int)sizeof(float);
-        if (int rc = lds_opt_in(opt, (const void *)k_cond_fwd1<C>, 160 * 1024 - 256)) return rc;
         if (int rc = lds_opt_in(opt2, (const void *)k_cond_fwd2<C>, 160 * 1024 - 256)) return rc;
-        if (IFL_COND_MFMA_HIDDEN) {
+        {
             using Hc = HCfg<C>;
             static LdsOptIn optm;
             constexpr int a_m = Hc::P_FL + Hc::A_FL + Hc::T_FL, b_m = 8 * Hc::MT2 * 4 * 64 * 4;
@@ -1009,41 +807,36 @@ template <int C> struct CondLaunch {
             static_assert(ldsm <= 160 * 1024 - 256, "forward 1 fits the LDS");
             if (int rc = lds_opt_in(optm, (const void *)k_cond_fwd1m<C>, 160 * 1024 - 256)) return rc;
             hipLaunchKernelGGL(k_cond_fwd1m<C>, dim3(tiles), dim3(512), ldsm, st, x, w1, w2, a2, s);
-        } else
-            hipLaunchKernelGGL(k_cond_fwd1<C>, dim3(tiles), dim3(64 * J), lds, st, x, wt, a2, s, J);
+        }
         hipLaunchKernelGGL(k_cond_fwd2<C>, dim3(tiles), dim3(64 * JC), ldsc, st, (const float *)a2, wt, b3, h, s);
         IFL_HIP(hipGetLastError());
         return IFL_OK;
     }
     template <class T>
     static int backward(const float *x, const float *dh, const float *h, const float *a2, const float *wt, const float *w1,
-                        const float *w2, void *ws,
-                        float *grads, float *dx, CondShape s, float logscale, hipStream_t st)
+                        void *ws, float *grads, float *dx, CondShape s, float logscale, hipStream_t st)
     {
-        static LdsOptIn opt1, opt2, opt3;
-        const int NPX = s.B * s.H * s.W, tiles = (NPX + 63) / 64, J = pick_j(s.Wd), P = tiles * 64;
+        static LdsOptIn opt1, opt3;
+        const int NPX = s.B * s.H * s.W, tiles = (NPX + 63) / 64, P = tiles * 64;
         const CondWs w = cond_ws(C, s.Wd, P, sizeof(T));
         char *b = (char *)ws;
         T *g3t = (T *)(b + w.ops), *p3t = g3t + (size_t)C * P, *g2t = p3t + (size_t)9 * C * P, *a1t = g2t + (size_t)C * P;
         T *g1t = a1t + (size_t)s.Wd * P, *p1t = g1t + (size_t)s.Wd * P;
         float *u = (float *)(b + w.u), *tpart = (float *)(b + w.tpart), *gpart = (float *)(b + w.gpart);
         constexpr int JC = CSplit<C>::JC, ldsc = (JC * C * 64 + JC * STAGE) * (int)sizeof(float);
-        const int lds2 = (K1 * 64 + J * STAGE + C * 64) * (int)sizeof(float);
         constexpr int lds3 = UCfg<C>::LDS_FL * (int)sizeof(float);
         if (int rc = lds_opt_in(opt1, (const void *)k_cond_bwd1<C, T>, 160 * 1024 - 256)) return rc;
-        if (int rc = lds_opt_in(opt2, (const void *)k_cond_bwd2<C, T>, 160 * 1024 - 256)) return rc;
         if (int rc = lds_opt_in(opt3, (const void *)k_cond_bwd3u<C, T>, 160 * 1024 - 256)) return rc;
         hipLaunchKernelGGL((k_cond_bwd1<C, T>), dim3(tiles), dim3(64 * JC), ldsc, st, dh, h, a2, wt, g3t, p3t, g2t, tpart, s, P, logscale);
-        if (IFL_COND_MFMA_HIDDEN) {
+        {
             using Hc = HCfg<C>;
             static LdsOptIn optm;
             constexpr int ldsm = (Hc::P_FL + Hc::A_FL + (C + 3) / 4 * 4 * Hc::PST) * (int)sizeof(float);
             static_assert(ldsm <= 160 * 1024 - 256, "backward 2 fits the LDS");
             if (int rc = lds_opt_in(optm, (const void *)k_cond_bwd2m<C, T>, 160 * 1024 - 256)) return rc;
-            hipLaunchKernelGGL((k_cond_bwd2m<C, T>), dim3(tiles), dim3(512), ldsm, st, x, (const T *)g2t, w1,
-                               wt + (size_t)K1 * s.Wd, a1t, g1t, p1t, s, P);
-        } else
-            hipLaunchKernelGGL((k_cond_bwd2<C, T>), dim3(tiles), dim3(64 * J), lds2, st, x, (const T *)g2t, wt, w2, a1t, g1t, p1t, s, J, P);
+            hipLaunchKernelGGL((k_cond_bwd2m<C, T>), dim3(tiles), dim3(512), ldsm, st, x, (const T *)g2t, w1, wt + (size_t)K1 * s.Wd, a1t,
+                               g1t, p1t, s, P);
+        }
         hipLaunchKernelGGL((k_cond_bwd3u<C, T>), dim3(tiles), dim3(512), lds3, st, (const T *)g1t, wt, u, s.Wd, P);
         hipLaunchKernelGGL(k_cond_bwd3g<C>, dim3(tiles), dim3(256), 0, st, (const float *)u, dx, s, P);
         // the three weight gradients
@@ -1129,21 +922,21 @@ size_t ifl_cond_backward_workspace_bytes(int B, int C, int H, int W, int width, 
 size_t ifl_cond_grads_floats(int C, int width) { return (size_t)width * 9 * (C / 2) + (size_t)C * width + (size_t)9 * C * C + 2 * (size_t)C; }
 
 int ifl_cond_backward_f32(const float *x, int x_channels, const float *dh, const float *h, const float *a2, const float *wt,
-                          const float *w1, const float *w2, int operands_f32, void *ws, size_t ws_bytes, float *grads, float *dx, int B, int C, int H,
+                          const float *w1, int operands_f32, void *ws, size_t ws_bytes, float *grads, float *dx, int B, int C, int H,
                           int W, int width, float logscale_factor, ifl_stream_t stream)
 {
     clear_error();
     if (int rc = cond_check("ifl_cond_backward_f32", B, C, H, W, width, x_channels)) return rc;
     if (B == 0) return IFL_OK;
-    if (!x || !dh || !h || !a2 || !wt || !w1 || !w2 || !ws || !grads || !dx) IFL_FAIL(IFL_EINVAL, "ifl_cond_backward_f32: null pointer");
+    if (!x || !dh || !h || !a2 || !wt || !w1 || !ws || !grads || !dx) IFL_FAIL(IFL_EINVAL, "ifl_cond_backward_f32: null pointer");
     const size_t need = ifl_cond_backward_workspace_bytes(B, C, H, W, width, operands_f32);
     if (ws_bytes < need || ((uintptr_t)ws & 255)) IFL_FAIL(IFL_EWORKSPACE, "ifl_cond_backward_f32: %zu bytes of 256-aligned workspace needed", need);
     const CondShape s{B, H, W, width, x_channels};
     hipStream_t st = (hipStream_t)stream;
     if (operands_f32) {
-        IFL_COND_DISPATCH(C, template backward<float>(x, dh, h, a2, wt, w1, w2, ws, grads, dx, s, logscale_factor, st));
+        IFL_COND_DISPATCH(C, template backward<float>(x, dh, h, a2, wt, w1, ws, grads, dx, s, logscale_factor, st));
     }
-    IFL_COND_DISPATCH(C, template backward<bf16_t>(x, dh, h, a2, wt, w1, w2, ws, grads, dx, s, logscale_factor, st));
+    IFL_COND_DISPATCH(C, template backward<bf16_t>(x, dh, h, a2, wt, w1, ws, grads, dx, s, logscale_factor, st));
 }
 
 } // extern "C"

@@ -67,8 +67,7 @@ class _Affine(torch.autograd.Function):
 
 class _CondAffine(torch.autograd.Function):
     """(x, the conditioner's parameters) -> (y, sum log_s): conditioner and affine map on the library, forward and backward
-    (csrc/conditioner.hip: two launches for h = net(x1), three + three GEMMs for its backward, next to the affine map's
-    one each way).  fp32 arithmetic throughout -- under autocast too: the net's arithmetic is small, its launch count is
+    (csrc/conditioner.hip: two launches for h = net(x1), six for its backward, next to the affine map's one each way).  fp32 arithmetic throughout -- under autocast too: the net's arithmetic is small, its launch count is
     not; `lowp` (autocast on) only picks bf16 operand matrices for the three weight-gradient GEMMs."""
 
     @staticmethod
@@ -78,16 +77,17 @@ class _CondAffine(torch.autograd.Function):
         w1, w2 = w1.contiguous(), w2.contiguous()
         wt = H.cond_prep(w1, w2, w3.contiguous(), logs.contiguous(), logscale)
         a2, h = H.cond_forward(x, wt, w1, w2, b3, w3.shape[0], w1.shape[0])
-        ctx.save_for_backward(x, h, a2, wt, w1, w2)
+        ctx.save_for_backward(x, h, a2, wt, w1)
+        ctx.width = w1.shape[0]
         ctx.logscale, ctx.has_bias, ctx.lowp = logscale, b3 is not None, lowp
         return H.coupling(x, h)
 
     @staticmethod
     @_bwd32
     def backward(ctx, gy, gld):
-        x, h, a2, wt, w1, w2 = ctx.saved_tensors
+        x, h, a2, wt, w1 = ctx.saved_tensors
         gx, gh = H.coupling_backward(gy.contiguous(), gld.contiguous() if gld is not None else None, x, h)
-        dw1, dw2, dw3, dlogs, db3 = H.cond_backward(x, gh, h, a2, wt, w1, w2, gx, w2.shape[1], ctx.logscale, ctx.lowp)
+        dw1, dw2, dw3, dlogs, db3 = H.cond_backward(x, gh, h, a2, wt, w1, gx, ctx.width, ctx.logscale, ctx.lowp)
         return gx, dw1, dw2, dw3, (db3 if ctx.has_bias else None), dlogs, None, None
 
 

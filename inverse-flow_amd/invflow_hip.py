@@ -66,7 +66,7 @@ SIGNATURES = {
     "ifl_cond_forward_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ifl_cond_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "ifl_cond_grads_floats": (_sz, [_i, _i]),
-    "ifl_cond_backward_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "ifl_cond_backward_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "ifl_coupling_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ifl_coupling_backward_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ifl_activation_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -644,22 +644,22 @@ def cond_forward(x, wt, w1, w2, b3, C, width):
     return a2, h
 
 
-def cond_backward(x, dh, h, a2, wt, w1, w2, dx, width, logscale_factor, low_precision=False):
+def cond_backward(x, dh, h, a2, wt, w1, dx, width, logscale_factor, low_precision=False):
     """dx[:, :C/2] += the input gradient (in place); returns (dW1, dW2, dW3, d logs, d b3) (views of one buffer).
     low_precision (the bf16 autocast step): the operand matrices of the three weight-gradient products are bf16."""
     B, Cx, H, W = _chk4(x, "input")
     C = h.shape[1]
-    for t, n in ((dh, "grad_h"), (h, "h"), (a2, "a2"), (wt, "weights"), (w1, "w1"), (w2, "w2"), (dx, "grad_input")):
+    for t, n in ((dh, "grad_h"), (h, "h"), (a2, "a2"), (wt, "weights"), (w1, "w1"), (dx, "grad_input")):
         _chk_tensor(t, n)
     if dh.shape != h.shape or a2.shape != h.shape or dx.shape != x.shape:
         raise RuntimeError("conditioner backward: shapes do not match the forward's")
-    dev = _same_device(x, dh, h, a2, wt, w2, dx)
+    dev = _same_device(x, dh, h, a2, wt, w1, dx)
     f32 = 0 if low_precision else 1
     nb = lib().ifl_cond_backward_workspace_bytes(B, C, H, W, width, f32)
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)  # (fresh: lives until the kernels of this call have run)
     grads = torch.empty(lib().ifl_cond_grads_floats(C, width), dtype=torch.float32, device=dev)
     with _on(dev):
-        rc = lib().ifl_cond_backward_f32(_ptr(x), Cx, _ptr(dh), _ptr(h), _ptr(a2), _ptr(wt), _ptr(w1), _ptr(w2), f32, _ptr(ws), nb,
+        rc = lib().ifl_cond_backward_f32(_ptr(x), Cx, _ptr(dh), _ptr(h), _ptr(a2), _ptr(wt), _ptr(w1), f32, _ptr(ws), nb,
                                          _ptr(grads),
                                          _ptr(dx), B, C, H, W, width, float(logscale_factor), _stream())
     _check(rc, "ifl_cond_backward_f32")

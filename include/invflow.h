@@ -58,7 +58,8 @@ enum { IFL_OP_INVERSE = 0, IFL_OP_FORWARD = 1, IFL_OP_BACKWARD = 2, IFL_OP_DY = 
 /* Library / ABI version (major*1000 + minor).
  * 2.0 (2000): every entry point that scans takes the caller's `scan_state` block as an argument (there is no registry inside
  *   the library); ifl_inverse_* rejects z aliasing x with IFL_EINVAL (the scans read x while z rows are already leaving);
- *   *recon_loss RECEIVES the loss on every route (the library clears it; it does not accumulate into the caller's value). */
+ *   *recon_loss RECEIVES the loss on every route (the library clears it; it does not accumulate into the caller's value).
+ * 2.1 (2100): + ifl_cond_* (the conditioner of the affine coupling); nothing else changes. */
 int ifl_version(void);
 
 /* Message of the last failing call made by this thread ("" if none). */

@@ -305,7 +305,7 @@ int inverse_io(const ScanIO &io, const float *w, int B, int C, int H, int W, int
 
 extern "C" {
 
-int ifl_version(void) { return 2000; }
+int ifl_version(void) { return 2100; }
 
 void ifl_profile_enable(int on)
 {

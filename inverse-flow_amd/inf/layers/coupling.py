@@ -67,8 +67,9 @@ class _Affine(torch.autograd.Function):
 
 class _CondAffine(torch.autograd.Function):
     """(x, the conditioner's parameters) -> (y, sum log_s): conditioner and affine map on the library, forward and backward
-    (csrc/conditioner.hip: two launches for h = net(x1), six for its backward, next to the affine map's one each way).  fp32 arithmetic throughout -- under autocast too: the net's arithmetic is small, its launch count is
-    not; `lowp` (autocast on) only picks bf16 operand matrices for the three weight-gradient GEMMs."""
+    (csrc/conditioner.hip: two launches for h = net(x1), six for its backward, next to the affine map's one each way).
+    fp32 arithmetic throughout -- under autocast too: the net's arithmetic is small, its launch count is not; `lowp`
+    (autocast on) only picks bf16 operand matrices for the three weight-gradient products."""
 
     @staticmethod
     @_fwd32

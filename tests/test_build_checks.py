@@ -224,6 +224,28 @@ def test_wide_kernels_fit_their_launches(tmp_path):
         assert m["vgpr"] <= 256, (name, m)
 
 
+def test_conditioner_kernels_do_not_spill(tmp_path):
+    """conditioner.hip: the first forms of these kernels spilled up to 2.8 KB a lane (fully unrolled blocks of uniform-address
+    LDS reads are hoisted to the top whatever the fences say: DESIGN 4.4b); every kernel of the file must compile without a
+    spilled register or a byte of scratch, within the 256 registers two waves per SIMD leave a lane, and no load of an
+    activation may sit in a divergent branch (a branch per load serialises the round trips) -- counted here as: no kernel has
+    more exec-mask branches than a fixed small number."""
+    out = str(tmp_path / "conditioner.s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-Wno-inline-asm", "-S",
+                    "--cuda-device-only", "-o", out, os.path.join(PKG, "csrc", "conditioner.hip")], check=True, stdout=subprocess.PIPE,
+                   stderr=subprocess.PIPE)
+    bodies, meta = kernels(open(out).read())
+    cond = {k: v for k, v in meta.items() if "k_cond_" in k}
+    # prep, wreduce, wgrad x 2 operand types, and per channel count (7): fwd1m, fwd2, bwd3g, and x 2 operand types bwd1, bwd2m, bwd3u
+    assert len(cond) == 2 + 2 + 7 * (3 + 2 * 3), sorted(cond)
+    for name, m in cond.items():
+        assert m["spill"] == 0 and m["scratch"] == 0 and m["vgpr"] <= 256, (name, m)
+        assert not any(re.match(r"\s*(scratch_|buffer_(load|store))", ln) for ln in bodies[name]), name
+        if "k_cond_bwd1" in name or "k_cond_fwd2" in name:  # the two kernels with 9 x NI neighbourhood loads per lane
+            n_br = sum(1 for ln in bodies[name] if re.match(r"\s*s_cbranch_execz", ln))
+            assert n_br <= 30, (name, n_br)  # (the staging copies have a few; a branch per load would be 9 per channel)
+
+
 def _vregs(tok):
     """v5 -> {5}; v[4:7] -> {4, 5, 6, 7}"""
     m = re.fullmatch(r"v(\d+)", tok)

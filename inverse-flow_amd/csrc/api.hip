@@ -252,8 +252,7 @@ static int run_scan(const ScanIO &io, const float *w, const Geom &g, int transpo
     }
     {
         ProfScope ps(IFL_PROF_FOLD, s);
-        if ((rc = launch_linv(w, linv, g, s))) return rc;
-        if ((rc = launch_fold(w, linv, wf, g, transposed, s))) return rc;
+        if ((rc = launch_linv_fold(w, linv, wf, g, transposed, s))) return rc;
     }
     ProfScope ps(IFL_PROF_SCAN, s);
     if (scan_resident_supported(g)) return launch_scan_resident(x, wf, z, g, rh, rw, s);

@@ -823,60 +823,68 @@ __global__ __launch_bounds__(64) void k_table_sums(const float *__restrict__ tpa
 }
 
 // ---- knot tables of the shared-weight spline from its parameters (rational_quadratic.py:35-46,97-116) and the way back.
-// 3 n_bins - 1 numbers in, 3 (n_bins + 1) out: one thread; replaces ~25 eager launches each way.
+// 3 n_bins - 1 numbers in, 3 (n_bins + 1) out; replaces ~25 eager launches each way.  One wave: lane i of each half owns bin i
+// of the widths / heights (the exponentials and logarithms run side by side -- as one serial thread these two kernels took
+// 9-10 us each, 31-144 times a step); every sum is still added by one lane in the serial code's order, so the results are the
+// same bits.
 //   cw_j = 2T cum_j - T,  cum_j = sum_{i<j} (m + (1 - m K) softmax(uw)_i),  cw_0 = -T, cw_K = T   (ch likewise from uh)
 //   dv_j = m + softplus(ud_{j-1} + c) for 0 < j < K,  dv_0 = dv_K = m + softplus(c),  c = log(e^{1-m} - 1),  m = 1e-6
-__global__ void k_rq_tables(const float *__restrict__ uw, const float *__restrict__ uh, const float *__restrict__ ud,
-                            float *__restrict__ cw, float *__restrict__ ch, float *__restrict__ dv, int K, float T)
+__global__ __launch_bounds__(64) void k_rq_tables(const float *__restrict__ uw, const float *__restrict__ uh, const float *__restrict__ ud,
+                                                  float *__restrict__ cw, float *__restrict__ ch, float *__restrict__ dv, int K, float T)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __shared__ float ex[2][32];
+    if (blockIdx.x != 0) return;
+    const int which = threadIdx.x >> 5, i = threadIdx.x & 31;
     const float m = 1e-6f, c = logf(expf(1.0f - m) - 1.0f);
-    for (int which = 0; which < 2; ++which) {
-        const float *u = which ? uh : uw;
-        float *out = which ? ch : cw;
-        float mx = u[0];
-        for (int i = 1; i < K; ++i) mx = fmaxf(mx, u[i]);
-        float den = 0.f;
-        for (int i = 0; i < K; ++i) den += expf(u[i] - mx);
+    const float *u = which ? uh : uw;
+    float *out = which ? ch : cw;
+    float mx = u[0];
+    for (int t = 1; t < K; ++t) mx = fmaxf(mx, u[t]);
+    if (i < K) ex[which][i] = expf(u[i] - mx);
+    __syncthreads();
+    float den = 0.f;
+    for (int t = 0; t < K; ++t) den += ex[which][t];
+    if (i < K) {
         float cum = 0.f;
-        out[0] = -T;
-        for (int i = 0; i < K; ++i) {
-            cum += m + (1.0f - m * K) * (expf(u[i] - mx) / den);
-            out[i + 1] = i + 1 == K ? T : 2.0f * T * cum - T;
-        }
+        for (int t = 0; t <= i; ++t) cum += m + (1.0f - m * K) * (ex[which][t] / den);
+        out[i + 1] = i + 1 == K ? T : 2.0f * T * cum - T;
     }
-    for (int j = 0; j <= K; ++j) {
-        const float a = (j == 0 || j == K) ? c : ud[j - 1] + c;
-        dv[j] = m + (fmaxf(a, 0.f) + log1pf(expf(-fabsf(a))));
+    if (i == 0) out[0] = -T;
+    if (which == 0 && i <= K) {
+        const float a = (i == 0 || i == K) ? c : ud[i - 1] + c;
+        dv[i] = m + (fmaxf(a, 0.f) + log1pf(expf(-fabsf(a))));
     }
 }
 // g_tables = (g_cw, g_ch, g_dv), 3 (K + 1) floats -> gradients of the parameters
-__global__ void k_rq_tables_bwd(const float *__restrict__ gt, const float *__restrict__ uw, const float *__restrict__ uh,
-                                const float *__restrict__ ud, float *__restrict__ guw, float *__restrict__ guh,
-                                float *__restrict__ gud, int K, float T)
+__global__ __launch_bounds__(64) void k_rq_tables_bwd(const float *__restrict__ gt, const float *__restrict__ uw,
+                                                      const float *__restrict__ uh, const float *__restrict__ ud, float *__restrict__ guw,
+                                                      float *__restrict__ guh, float *__restrict__ gud, int K, float T)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __shared__ float pr[2][32], gv[2][32];
+    if (blockIdx.x != 0) return;
+    const int which = threadIdx.x >> 5, i = threadIdx.x & 31;
     const float m = 1e-6f, c = logf(expf(1.0f - m) - 1.0f);
-    for (int which = 0; which < 2; ++which) {
-        const float *u = which ? uh : uw;
-        const float *g = gt + which * (K + 1);
-        float *out = which ? guh : guw;
-        float mx = u[0];
-        for (int i = 1; i < K; ++i) mx = fmaxf(mx, u[i]);
-        float den = 0.f;
-        for (int i = 0; i < K; ++i) den += expf(u[i] - mx);
-        // g_v_i = (1 - m K) 2T sum_{j = i+1}^{K-1} g_knot_j  (the end knots are constants)
-        float dot = 0.f, tail = 0.f;
-        float gv[RQ_MAXB];
-        for (int i = K - 1; i >= 0; --i) {
-            gv[i] = (1.0f - m * K) * 2.0f * T * tail;
-            if (i >= 1) tail += g[i]; // knot i is fed by v_0 .. v_{i-1}
-        }
-        for (int i = 0; i < K; ++i) dot += (expf(u[i] - mx) / den) * gv[i];
-        for (int i = 0; i < K; ++i) out[i] = (expf(u[i] - mx) / den) * (gv[i] - dot);
+    const float *u = which ? uh : uw;
+    const float *g = gt + which * (K + 1);
+    float *out = which ? guh : guw;
+    float mx = u[0];
+    for (int t = 1; t < K; ++t) mx = fmaxf(mx, u[t]);
+    if (i < K) pr[which][i] = expf(u[i] - mx);
+    __syncthreads();
+    float den = 0.f;
+    for (int t = 0; t < K; ++t) den += pr[which][t];
+    // g_v_i = (1 - m K) 2T sum_{j = i+1}^{K-1} g_knot_j  (the end knots are constants; added from the last knot down)
+    if (i < K) {
+        float tail = 0.f;
+        for (int t = K - 1; t > i; --t) tail += g[t];
+        gv[which][i] = (1.0f - m * K) * 2.0f * T * tail;
     }
+    __syncthreads();
+    float dot = 0.f;
+    for (int t = 0; t < K; ++t) dot += (pr[which][t] / den) * gv[which][t];
+    if (i < K) out[i] = (pr[which][i] / den) * (gv[which][i] - dot);
     const float *gd = gt + 2 * (K + 1);
-    for (int j = 1; j < K; ++j) gud[j - 1] = gd[j] / (1.0f + expf(-(ud[j - 1] + c)));
+    if (which == 1 && i >= 1 && i < K) gud[i - 1] = gd[i] / (1.0f + expf(-(ud[i - 1] + c)));
 }
 
 

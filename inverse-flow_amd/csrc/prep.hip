@@ -170,6 +170,61 @@ __global__ void k_fold(const float *__restrict__ w, const double *__restrict__ l
     }
 }
 
+// Small layers (C <= 16: the 4- and 8-channel layers of the MNIST Glow run 64 of these preparations a step): L^-1 and the
+// folded taps in ONE launch -- k_linv_lds's recurrence, then k_fold's sums with L^-1 read from LDS; the same arithmetic in the
+// same order, the same bits.
+__global__ __launch_bounds__(256) void k_linv_fold_small(const float *__restrict__ w, double *__restrict__ linv, float *__restrict__ wf,
+                                                         Geom g, int transposed)
+{
+    __shared__ double sl[16 * 16];
+    __shared__ float sL[16 * 16];
+    const int C = g.C;
+    for (int idx = threadIdx.x; idx < C * C; idx += blockDim.x) sL[idx] = (float)l_entry(w, idx / C, idx % C, g);
+    __syncthreads();
+    const int j = threadIdx.x;
+    if (j < C) {
+        for (int i = 0; i < C; ++i) {
+            double v = 0.0;
+            if (i >= j) {
+                double a = (i == j) ? 1.0 : 0.0;
+                for (int k = j; k < i; ++k) a -= (double)sL[i * C + k] * sl[k * C + j];
+                v = a / (double)sL[i * C + i];
+            }
+            sl[i * C + j] = v;
+            linv[(size_t)i * C + j] = v;
+        }
+    }
+    __syncthreads();
+    const int total = g.KH * g.KW * C * C;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const int c = i % C, kc = (i / C) % C, t = i / (C * C);
+        const int dh = t / g.KW, dw = t % g.KW;
+        double acc;
+        if (t == 0) {
+            acc = transposed ? sl[kc * C + c] : sl[c * C + kc];
+        } else {
+            acc = 0.0;
+            if (!transposed) {
+                for (int m = 0; m <= c; ++m) acc += sl[c * C + m] * (double)w[w_index(m, kc, dh, dw, C, g.KH, g.KW, g.flipH, g.flipW)];
+            } else {
+                for (int m = c; m < C; ++m) acc += sl[m * C + c] * (double)w[w_index(kc, m, dh, dw, C, g.KH, g.KW, g.flipH, g.flipW)];
+            }
+        }
+        wf[i] = (float)acc;
+    }
+}
+
+int launch_linv_fold(const float *w, double *linv, float *wf, const Geom &g, int transposed, hipStream_t s)
+{
+    if (g.C <= 16) {
+        hipLaunchKernelGGL(k_linv_fold_small, dim3(1), dim3(256), 0, s, w, linv, wf, g, transposed);
+        IFL_HIP(hipGetLastError());
+        return IFL_OK;
+    }
+    if (int rc = launch_linv(w, linv, g, s)) return rc;
+    return launch_fold(w, linv, wf, g, transposed, s);
+}
+
 int launch_fold(const float *w, const double *linv, float *wf, const Geom &g, int transposed, hipStream_t s)
 {
     const size_t total = (size_t)g.KH * g.KW * g.C * g.C;

@@ -74,7 +74,7 @@ static inline Geom make_geom(int B, int C, int H, int W, int KH, int KW, int ord
 // ---- prep kernels (prep.hip) ---------------------------------------------------------------
 // Linv = L^-1 (double, row-major CxC), L = diagonal-tap matrix of What (unit or general diagonal).
 int launch_linv(const float *w, double *linv, const Geom &g, hipStream_t s);
-int launch_linv_fold(const float *w, double *linv, float *wf, const Geom &g, int transposed, hipStream_t s); // both, one launch for C <= 16
+int launch_linv_fold(const float *w, double *linv, float *wf, const Geom &g, int transposed, hipStream_t s); // both, one launch for C <= 32
 // Folded taps Wf[t][kc][c] (float), t = dh*KW+dw:  t=0 -> L^-1 (x tap), t>0 -> L^-1 What_t.
 // transposed!=0 builds the taps of A^T (for dx = A^-T g): L^-T and L^-T What_t^T.
 int launch_fold(const float *w, const double *linv, float *wf, const Geom &g, int transposed, hipStream_t s);

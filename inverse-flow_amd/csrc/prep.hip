@@ -170,14 +170,14 @@ __global__ void k_fold(const float *__restrict__ w, const double *__restrict__ l
     }
 }
 
-// Small layers (C <= 16: the 4- and 8-channel layers of the MNIST Glow run 64 of these preparations a step): L^-1 and the
+// Small layers (C <= 32: the 4- and 8-channel layers of the MNIST Glow run 64 of these preparations a step): L^-1 and the
 // folded taps in ONE launch -- k_linv_lds's recurrence, then k_fold's sums with L^-1 read from LDS; the same arithmetic in the
 // same order, the same bits.
 __global__ __launch_bounds__(256) void k_linv_fold_small(const float *__restrict__ w, double *__restrict__ linv, float *__restrict__ wf,
                                                          Geom g, int transposed)
 {
-    __shared__ double sl[16 * 16];
-    __shared__ float sL[16 * 16];
+    __shared__ double sl[32 * 32];
+    __shared__ float sL[32 * 32];
     const int C = g.C;
     for (int idx = threadIdx.x; idx < C * C; idx += blockDim.x) sL[idx] = (float)l_entry(w, idx / C, idx % C, g);
     __syncthreads();
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void k_linv_fold_small(const float *__restrict
 
 int launch_linv_fold(const float *w, double *linv, float *wf, const Geom &g, int transposed, hipStream_t s)
 {
-    if (g.C <= 16) {
+    if (g.C <= 32) {
         hipLaunchKernelGGL(k_linv_fold_small, dim3(1), dim3(256), 0, s, w, linv, wf, g, transposed);
         IFL_HIP(hipGetLastError());
         return IFL_OK;

@@ -25,6 +25,23 @@ def _accumulate(total, term):
     return total + term
 
 
+def _sum_terms(terms):
+    """the layers' log-dets added up: python numbers in python, tensors of one shape on one device by ONE stack + sum (a
+    model of a hundred layers otherwise spends a hundred launches of a B-element add on it), anything else one by one"""
+    total, same = 0.0, []
+    for t in terms:
+        if torch.is_tensor(t) and t.is_cuda and t.dim() == 1 and (not same or (t.shape == same[0].shape and t.device == same[0].device
+                                                                             and t.dtype == same[0].dtype)):
+            same.append(t)
+        else:
+            total = _accumulate(total, t)
+    if len(same) > 2:
+        return _accumulate(total, torch.stack(same).sum(0))
+    for t in same:
+        total = _accumulate(total, t)
+    return total
+
+
 class FlowSequential(nn.Module):
     def __init__(self, base_distribution, *modules):
         super().__init__()
@@ -39,11 +56,11 @@ class FlowSequential(nn.Module):
     # ---- the two directions --------------------------------------------------------------------------------------
     def _push(self, modules, tensor, context, compute_expensive):
         """forward through `modules`: (output, summed log-det)"""
-        logdet = 0.0
+        terms = []
         for module in modules:
             tensor, term = _apply(module, "forward", tensor, context, compute_expensive)
-            logdet = _accumulate(logdet, term)
-        return tensor, logdet
+            terms.append(term)
+        return tensor, _sum_terms(terms)
 
     def _pull(self, tensor, context, compute_expensive):
         """reverse through all modules, last first"""

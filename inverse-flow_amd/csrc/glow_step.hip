@@ -52,8 +52,10 @@ __device__ __forceinline__ float block_sum(float v, float *sh)
 // one workgroup per (image, channel) plane; reverse: y = x exp(ls) + t  (actnorm.py:40-54)
 template <class T>
 __global__ __launch_bounds__(GS_T) void k_actnorm(const T *__restrict__ x, const float *__restrict__ tr,
-                                                  const float *__restrict__ ls, T *__restrict__ y, int C, int HW, int reverse)
+                                                  const float *__restrict__ ls, T *__restrict__ y, int C, int HW, int reverse,
+                                                  float *__restrict__ logdet, int B)
 {
+    __shared__ float sh[4];
     const size_t plane = blockIdx.x;
     const int c = (int)(plane % C);
     const float t = tr[c], l = ls[c];
@@ -69,20 +71,15 @@ __global__ __launch_bounds__(GS_T) void k_actnorm(const T *__restrict__ x, const
     } else {
         for (int i = threadIdx.x; i < HW; i += GS_T) put(yp + i, fmaf(widen(xp[i]), sc, of));
     }
+    if (logdet && blockIdx.x == 0) { // logdet[b] = -HW sum_c ls_c (actnorm.py:59-67): the first workgroup, behind its plane
+        float a = 0.f;
+        for (int cc = threadIdx.x; cc < C; cc += GS_T) a += ls[cc];
+        const float s = -block_sum(a, sh) * (float)HW;
+        for (int b = threadIdx.x; b < B; b += GS_T) logdet[b] = s;
+    }
 }
 // note on rounding: the reference computes (x - t) * exp(-ls); x*sc - t*sc differs by one rounding of t*sc
 // (relative 6e-8 of |t sc|): inside the 1e-5 tolerance of the path, and one FMA instead of two operations.
-
-// logdet[b] = -HW sum_c ls_c (actnorm.py:59-67); one workgroup, B outputs
-__global__ __launch_bounds__(GS_T) void k_actnorm_logdet(const float *__restrict__ ls, float *__restrict__ logdet, int B,
-                                                         int C, int HW)
-{
-    __shared__ float sh[4];
-    float a = 0.f;
-    for (int c = threadIdx.x; c < C; c += GS_T) a += ls[c];
-    const float s = -block_sum(a, sh) * (float)HW;
-    for (int b = threadIdx.x; b < B; b += GS_T) logdet[b] = s;
-}
 
 // backward, stage 1: gx = gy exp(-ls); partial[plane] = {sum gy, sum gy x} over the plane
 template <class T>
@@ -359,8 +356,7 @@ static int actnorm_impl(const char *who, const T *x, const float *translation, c
     if (!x || !translation || !log_scale || !y) IFL_FAIL(IFL_EINVAL, "%s: null pointer", who);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_actnorm<T>, dim3((unsigned)((size_t)B * C)), dim3(GS_T), 0, s, x, translation, log_scale, y, C, H * W,
-                       reverse);
-    if (logdet && !reverse) hipLaunchKernelGGL(k_actnorm_logdet, dim3(1), dim3(GS_T), 0, s, log_scale, logdet, B, C, H * W);
+                       reverse, reverse ? (float *)nullptr : logdet, B);
     IFL_HIP(hipGetLastError());
     return IFL_OK;
 }

@@ -59,7 +59,7 @@ enum { IFL_OP_INVERSE = 0, IFL_OP_FORWARD = 1, IFL_OP_BACKWARD = 2, IFL_OP_DY = 
  * 2.0 (2000): every entry point that scans takes the caller's `scan_state` block as an argument (there is no registry inside
  *   the library); ifl_inverse_* rejects z aliasing x with IFL_EINVAL (the scans read x while z rows are already leaving);
  *   *recon_loss RECEIVES the loss on every route (the library clears it; it does not accumulate into the caller's value).
- * 2.1 (2100): + ifl_cond_* (the conditioner of the affine coupling); nothing else changes. */
+ * 2.1 (2100): + ifl_cond_* (the conditioner of the affine coupling), ifl_adam_flat_f32; nothing else changes. */
 int ifl_version(void);
 
 /* Message of the last failing call made by this thread ("" if none). */
@@ -284,6 +284,13 @@ size_t ifl_cond_grads_floats(int C, int width);
 int ifl_cond_backward_f32(const float *x, int x_channels, const float *dh, const float *h, const float *a2, const float *wt,
                           const float *w1, int operands_f32, void *ws, size_t ws_bytes, float *grads, float *dx, int B, int C, int H,
                           int W, int width, float logscale_factor, ifl_stream_t stream);
+
+/* ---- optimizer step over a flat parameter buffer (the train step: inf/train/experiment.py:272-311 calls optimizer.step()) ----
+ * Adam (decoupled = 0: weight decay added to the gradient) / AdamW (decoupled = 1) with torch.optim's arithmetic on n
+ * contiguous floats: p, m = exp_avg, v = exp_avg_sq updated in place from g.  *lr and *step (the number of this step, from 1,
+ * as a float) are read on the device.  One elementwise pass where a multi-tensor optimizer takes a launch per 36 tensors. */
+int ifl_adam_flat_f32(float *p, const float *g, float *m, float *v, size_t n, const float *lr, const float *step, float beta1,
+                      float beta2, float eps, float weight_decay, int decoupled, ifl_stream_t stream);
 
 /* ---- activations of the Glow step (inf/layers/activations.py) ----------------------------------------------------- */
 size_t ifl_activation_workspace_bytes(int B, int C, int n_bins); /* scratch of the calls below (n_bins = 0: SmoothLeakyRelu) */

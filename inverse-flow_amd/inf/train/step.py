@@ -48,7 +48,7 @@ class TrainStep:
 
     def __init__(self, model, optimizer, add_recon_grad=False, grad_clip_norm=None, grad_clip=None, clear_grads=False,
                  autocast=False, bucket=True, graph=False, graph_warmup=3, force_collective=False, conv_search=False,
-                 fused_optimizer=True, gather_grads=None):
+                 fused_optimizer=True, gather_grads=None, flat_optimizer=None):
         self.model, self.optimizer = model, optimizer
         self.add_recon_grad, self.grad_clip_norm, self.grad_clip = add_recon_grad, grad_clip_norm, grad_clip
         self.clear_grads, self.autocast = clear_grads, autocast
@@ -75,6 +75,9 @@ class TrainStep:
             self._make_capturable()
             if fused_optimizer:
                 self._fuse_optimizer()
+        self._flat = None
+        if graph if flat_optimizer is None else flat_optimizer:
+            self._flatten_optimizer()
 
     def _make_capturable(self):
         """A captured optimizer step bakes every Python number it sees into its kernels.  The learning rate therefore
@@ -112,6 +115,60 @@ class TrainStep:
                 continue
             if all(p.is_cuda and torch.is_floating_point(p) for p in group["params"]):
                 group["foreach"], group["fused"] = False, True
+
+    def _flatten_optimizer(self):
+        """Adam / AdamW as ONE elementwise pass (ifl_adam_flat_f32) over a flat parameter buffer laid out like the gradient
+        bucket.  torch's fused multi-tensor Adam takes 36 tensors a launch: the configs[4] model's 1 300 tensors are 45
+        launches of ~48 us (2.2 ms a step) for what is 235 MB of traffic.  The parameters are re-homed as views of the flat
+        buffer (same values, same modules, same state_dict); exp_avg / exp_avg_sq are views of two more, entered in the
+        optimizer's state so that its state_dict() stays a torch.optim one.  Parameters that share their storage with
+        another parameter (Conv2dZero's bias and logs, as in the reference) keep it and a small fused optimizer of their
+        own; their slots in the flat buffers are unused.  Anything else (several parameter groups, amsgrad, CPU, an
+        optimizer with state, parameters outside the bucket) keeps the optimizer as it is."""
+        import invflow_hip as H
+        opt, bucket = self.optimizer, self.bucket
+        if bucket is None or not isinstance(opt, (torch.optim.Adam, torch.optim.AdamW)) or opt.state or len(opt.param_groups) != 1:
+            return
+        g = opt.param_groups[0]
+        params = [p for p in g["params"] if p.requires_grad]
+        if g.get("amsgrad") or g.get("maximize") or g.get("differentiable") or len(params) != len(bucket.params) or \
+                any(a is not b for a, b in zip(params, bucket.params)) or not all(p.is_cuda and p.dtype == torch.float32 for p in params):
+            return
+        dev = bucket.flat.device
+        lr = g["lr"] if torch.is_tensor(g["lr"]) else torch.tensor(float(g["lr"]), dtype=torch.float32, device=dev)
+        g["lr"] = lr
+        users = {}
+        for p in params:
+            users[p.untyped_storage().data_ptr()] = users.get(p.untyped_storage().data_ptr(), 0) + 1
+        flat_p, m, v = torch.zeros_like(bucket.flat), torch.zeros_like(bucket.flat), torch.zeros_like(bucket.flat)
+        step_t = torch.zeros((), dtype=torch.float32, device=dev)
+        off, shared = 0, []
+        for p in params:
+            n = p.numel()
+            if users[p.untyped_storage().data_ptr()] == 1 and p.is_contiguous():
+                dst = flat_p[off:off + n].view_as(p)
+                dst.copy_(p.data)
+                p.data = dst
+                opt.state[p] = {"step": step_t, "exp_avg": m[off:off + n].view_as(p), "exp_avg_sq": v[off:off + n].view_as(p)}
+            else:
+                shared.append(p)
+            off += n
+        rest = None
+        if shared:
+            rest = type(opt)(shared, lr=lr, betas=g["betas"], eps=g["eps"], weight_decay=g["weight_decay"], capturable=True, fused=True)
+        self._flat = dict(p=flat_p, m=m, v=v, step=step_t, lr=lr, rest=rest, H=H, decoupled=isinstance(opt, torch.optim.AdamW))
+
+    def _optimizer_step(self):
+        f = self._flat
+        if f is None:
+            self.optimizer.step()
+            return
+        g = self.optimizer.param_groups[0]
+        f["step"].add_(1.0)
+        f["H"].adam_flat(f["p"], self.bucket.flat, f["m"], f["v"], f["lr"].reshape(1), f["step"].reshape(1), g["betas"][0], g["betas"][1],
+                         g["eps"], g["weight_decay"], f["decoupled"])
+        if f["rest"] is not None:
+            f["rest"].step()
 
     def set_lr(self, lr):
         """change the learning rate of every parameter group -- in place when it is a device tensor (graph=True), so that a
@@ -221,7 +278,7 @@ class TrainStep:
             for p in self.model.parameters():
                 if p.grad is not None:
                     p.data.clamp_(-self.grad_clip, self.grad_clip)
-        self.optimizer.step()
+        self._optimizer_step()
 
     def _eager(self, x):
         lossval = self._backward_part(x)

@@ -59,6 +59,7 @@ SIGNATURES = {
     "ifl_actnorm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ifl_actnorm_backward_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ifl_squeeze_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ifl_adam_flat_f32": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _f, _f, _f, _f, _i, _vp]),
     "ifl_cond_supported": (_i, [_i, _i]),
     "ifl_cond_weights_floats": (_sz, [_i, _i]),
     "ifl_cond_pixels_padded": (_i, [_i, _i, _i]),
@@ -602,6 +603,19 @@ def coupling_backward(gy, g_logdet, x, h):
                                              _stream())
     _check(rc, "ifl_coupling_backward_" + sfx)
     return gx, gh
+
+
+def adam_flat(p, g, m, v, lr, step, beta1, beta2, eps, weight_decay=0.0, decoupled=False):
+    """one Adam / AdamW step over flat fp32 buffers, in place (lr, step: one-element device tensors)"""
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (lr, "lr"), (step, "step")):
+        _chk_tensor(t, n)
+    if not (p.numel() == g.numel() == m.numel() == v.numel()):
+        raise RuntimeError("adam_flat: buffers of different sizes")
+    dev = _same_device(p, g, m, v, lr, step)
+    with _on(dev):
+        rc = lib().ifl_adam_flat_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(lr), _ptr(step), float(beta1), float(beta2),
+                                     float(eps), float(weight_decay), 1 if decoupled else 0, _stream())
+    _check(rc, "ifl_adam_flat_f32")
 
 
 # ---- the coupling's conditioner (csrc/conditioner.hip) -----------------------------------------------------------------

@@ -293,3 +293,31 @@ def test_captured_step_with_the_bucket_all_reduce_inside(tmp_path):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "captured step with the collective: ok" in r.stdout, r.stdout[-3000:]
+
+
+def test_flat_adam_matches_the_multi_tensor_optimizer(fixture):
+    """TrainStep(graph=True) runs Adam as one pass over a flat parameter buffer (ifl_adam_flat_f32): parameters re-homed as
+    views, state entered in the optimizer.  Against the same steps on torch's fused multi-tensor Adam: the same losses and the
+    same parameters to rounding (1e-6 of each tensor's scale after 6 steps); the parameters are views of one buffer, the
+    shared-storage pair of every Conv2dZero keeps its storage, and the optimizer's state_dict has an entry per parameter."""
+    from inf.train.step import TrainStep
+    x = torch.from_numpy(fixture["x"]).float().cuda()
+    runs = []
+    for flat in (True, False):
+        torch.manual_seed(0)
+        model = build(fixture)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-4)
+        step = TrainStep(model, opt, grad_clip_norm=1.0, graph=True, graph_warmup=2, flat_optimizer=flat)
+        losses = [float(step(x)) for _ in range(6)]
+        runs.append((losses, [p.detach().clone() for p in model.parameters()], step, opt, model))
+    (l1, p1, step1, opt1, model1), (l0, p0, _, _, _) = runs
+    assert step1._flat is not None
+    assert np.allclose(l1, l0, rtol=1e-6, atol=0)
+    for a, b in zip(p1, p0):
+        assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
+    lo, hi = step1._flat["p"].data_ptr(), step1._flat["p"].data_ptr() + step1._flat["p"].numel() * 4
+    inside = [lo <= p.data_ptr() < hi for p in model1.parameters()]
+    assert sum(inside) >= len(inside) - 2 * sum(1 for m in model1.modules() if type(m).__name__ == "Conv2dZero") and any(inside)
+    sd = opt1.state_dict()["state"]
+    assert len(sd) == sum(inside) and all(set(v) == {"step", "exp_avg", "exp_avg_sq"} for v in sd.values())
+

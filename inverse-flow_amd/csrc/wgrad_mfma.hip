@@ -149,7 +149,24 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ a,
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int m = lane & 31, hh = lane >> 5;
-    const int blk = blockIdx.x % (NB * NB), split = blockIdx.x / (NB * NB);
+    // The NB x NB channel blocks of one split read the same image rows (block (p, q): channels p of a, q of bb).  Workgroups go
+    // to the 8 XCDs round robin (id mod 8) and every XCD has its own L2: numbered consecutively, a split's blocks sit on
+    // different XCDs and every operand row is fetched from memory NB times (rocprofv3 FETCH_SIZE, calibrated with
+    // tools/probes/fetch_size_probe.hip: 146 MB for the 67 MB of operands at the north-star shape).  So the blocks of a
+    // split are given ids of the same residue mod 8 -- they run at the same time on one XCD and share its L2.
+    int blk, split;
+    {
+        constexpr int NB2 = NB * NB;
+        const int w = blockIdx.x, nsplit = gridDim.x / NB2, full = (nsplit / 8) * 8 * NB2;
+        if (w < full) {
+            const int xcd = w & 7, j = w >> 3;
+            split = (j / NB2) * 8 + xcd;
+            blk = j % NB2;
+        } else {
+            blk = w % NB2;
+            split = w / NB2;
+        }
+    }
     const int bp = blk / NB, bq = blk % NB; // block row (a channels) / column (bb channels)
 
     // max|a|, max|bb| as float bit patterns (upper bounds are fine: they only pick a power-of-two scale)

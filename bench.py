@@ -220,6 +220,35 @@ def cifar_step_figure(dev, steps=10, warmup=5):
             "parameters": sum(p.numel() for p in model.parameters()), "steps": steps}
 
 
+def imagenet32_step_figure(dev, steps=6, warmup=5):
+    """BASELINE configs[4]: if_multiGPU_imagenet32 (inf/if_multiGPU_imagenet32.py:176-345: L = 3, K = 48, 3x3 inverse-flow
+    layers, shared splines, coupling width 256, no ActNorm) training step at one rank's shard of its batch of 100 over eight
+    GPUs (13 images), bf16 autocast, synthetic 32x32x3 images, one captured graph per step.  Not part of `value`."""
+    import torch
+    from inf.experiments.if_glow_imagenet32 import DEFAULT_CONFIG as cfg, create_model
+    from inf.train.step import TrainStep, bits_per_dim
+    torch.manual_seed(6)
+    model = create_model(inv_flow=cfg["inv_flow"], inv_conv=cfg["inv_conv"], inv_conv_no_pad=cfg["inv_conv_no_pad"],
+                         if_kernel_size=cfg["if_kernel_size"], num_blocks=cfg["num_blocks"], block_size=cfg["block_size"],
+                         coupling_width=cfg["coupling_width"], activation=cfg["activation"], actnorm=cfg["actnorm"],
+                         split_prior=cfg["split_prior"]).to(dev)
+    step = TrainStep(model, torch.optim.Adam(model.parameters(), lr=cfg["lr"]), grad_clip_norm=1.0, autocast=True, graph=True)
+    nb = 13
+    x = torch.randint(0, 256, (nb, 3, 32, 32), device=dev).float()
+    for _ in range(warmup):
+        loss = step(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step(x)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"config": "configs[4]: if_multiGPU_imagenet32 L=3, K=48, 3x3 inverse-flow layers, coupling width 256, 13 images per rank "
+                      "(100 over 8), 32x32x3, bf16 autocast, Adam, as configured (no ActNorm), synthetic data; one captured graph per step",
+            "ms_per_step": ms, "images_per_s": nb / (ms * 1e-3), "bits_per_dim": bits_per_dim(float(loss), 3 * 32 * 32),
+            "parameters": sum(p.numel() for p in model.parameters()), "steps": steps}
+
+
 def wide_layer_figure(dev, steps=50, warmup=10):
     """BASELINE configs[4]'s channel count: one 3x3 inverse-conv layer of C = 256 on 8x8 at the per-GPU batch 16 (the 100
     images of inf/if_multiGPU_imagenet32.py:294 over 8 GPUs, rounded up), inverse + fused backward like the headline step.
@@ -530,6 +559,7 @@ def main():
         if world == 1 and not args.no_train_step:
             out["train_step"] = train_step_figure(dev)
             out["train_step_cifar"] = cifar_step_figure(dev)
+            out["train_step_imagenet32"] = imagenet32_step_figure(dev)
             out["wide_layer"] = wide_layer_figure(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w_host)

@@ -285,11 +285,13 @@ def wide_layer_figure(dev, steps=50, warmup=10):
 def committed_counters(kernel_us, world):
     """HBM-side bytes and matrix-pipe busy fraction of the scan from the rocprofv3 --pmc passes of this same command whose
     summaries profiles/LATEST.json names (PMC counters cannot be read from inside this process).  None when there is no
-    pointer, or when the kernel it was taken on is not the one that just ran (other name, launch time off by > 15 %)."""
+    pointer, or when the kernel it was taken on cannot be the one that just ran (launch time off by > 25 %: the boxes of
+    this pool differ by +-10 % on the same binary -- 47 to 58 us for this kernel over round 3 -- and the bytes a launch moves
+    do not depend on the clock)."""
     try:
         with open(os.path.join(ROOT, "profiles", "LATEST.json")) as f:
             latest = json.load(f)
-        if world != 1 or abs(latest["scan_avg_us"] - kernel_us) > 0.15 * kernel_us:
+        if world != 1 or abs(latest["scan_avg_us"] - kernel_us) > 0.25 * kernel_us:
             return None, None, None
         traffic = (latest["fetch_size_kib"] * latest["fetch_correction"] + latest["write_size_kib"]) * 1024.0
         return traffic, latest.get("mfma_busy_frac"), latest.get("source")

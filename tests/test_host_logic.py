@@ -173,3 +173,30 @@ def test_gradient_masks_are_applied_in_place_and_stay_in_the_bucket():
         assert torch.equal(mods[2].conv.weight.grad, before[2] * mods[2].mask)
         bucket.zero()
         assert all(float(p.grad.abs().sum()) == 0.0 for p in mods.parameters())
+
+
+def test_bucket_release_and_gather():
+    """GradBucket.release() / gather() (TrainStep's captured backward writes fresh gradient tensors, one multi-tensor copy
+    brings them into the flat bucket): the bucket holds the gradients in parameter order, a parameter that received none
+    holds zeros, every .grad is a bucket view again -- and accumulating into the views afterwards lands in the bucket."""
+    import data_parallel as dp
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(2, 2, 2))]
+    bucket = dp.GradBucket(ps)
+    bucket.flat.fill_(7.0)
+    bucket.release()
+    assert all(p.grad is None for p in ps)
+    g0, g2 = torch.randn(3, 4), torch.randn(2, 2, 2)
+    ps[0].grad, ps[2].grad = g0, g2  # (the second parameter gets none)
+    bucket.gather()
+    lo, hi = bucket.flat.data_ptr(), bucket.flat.data_ptr() + bucket.flat.numel() * 4
+    assert all(lo <= p.grad.data_ptr() < hi for p in ps)
+    assert torch.equal(bucket.flat, torch.cat([g0.flatten(), torch.zeros(5), g2.flatten()]))
+    ps[1].grad.add_(1.0)
+    assert torch.equal(bucket.flat[12:17], torch.ones(5))
+    bucket.release()
+    for p, g in zip(ps, (g0, torch.ones(5), g2)):
+        p.grad = g.clone()
+    bucket.gather()  # (all present: no zero fill needed)
+    assert torch.equal(bucket.flat, torch.cat([g0.flatten(), torch.ones(5), g2.flatten()]))
+

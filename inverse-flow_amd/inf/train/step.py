@@ -195,7 +195,20 @@ class TrainStep:
         return self.bucket is not None and dp.dist.is_available() and dp.dist.is_initialized() and (
             dp.dist.get_world_size() > 1 or self.force_collective)
 
+    def _sync_lr(self):
+        """a scheduler that ASSIGNS group['lr'] (a Python number) instead of filling the device tensor: take the value into the
+        tensor the captured / flat optimizer step reads and put the tensor back"""
+        groups = self.optimizer.param_groups
+        if getattr(self, "_lr_t", None) is None or len(self._lr_t) != len(groups):
+            self._lr_t = [g["lr"] if torch.is_tensor(g["lr"]) and g["lr"].is_cuda else None for g in groups]
+        for g, t in zip(groups, self._lr_t):
+            if t is not None and g["lr"] is not t:
+                t.fill_(float(g["lr"]))
+                g["lr"] = t
+
     def __call__(self, x):
+        if self.graph:
+            self._sync_lr()
         if not self._ranks_agree:
             self._agree_on_init(x)
         if not self.graph or not x.is_cuda:

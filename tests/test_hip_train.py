@@ -251,6 +251,12 @@ def test_clear_grads_keeps_the_bucket_and_changes_nothing(fixture):
     before = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
     step(x)
     assert torch.equal(before, torch.cat([p.detach().reshape(-1) for p in model.parameters()]))
+    # ... also when a scheduler ASSIGNS a number to group['lr'] (torch's schedulers do): the value goes into the device tensor
+    lr_t = step.optimizer.param_groups[0]["lr"]
+    step.optimizer.param_groups[0]["lr"] = 1e-3
+    step(x)
+    assert step.optimizer.param_groups[0]["lr"] is lr_t and abs(float(lr_t) - 1e-3) < 1e-9
+    assert not torch.equal(before, torch.cat([p.detach().reshape(-1) for p in model.parameters()]))
 
 
 COLLECTIVE_WORKER = r'''

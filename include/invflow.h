@@ -59,7 +59,8 @@ enum { IFL_OP_INVERSE = 0, IFL_OP_FORWARD = 1, IFL_OP_BACKWARD = 2, IFL_OP_DY = 
  * 2.0 (2000): every entry point that scans takes the caller's `scan_state` block as an argument (there is no registry inside
  *   the library); ifl_inverse_* rejects z aliasing x with IFL_EINVAL (the scans read x while z rows are already leaving);
  *   *recon_loss RECEIVES the loss on every route (the library clears it; it does not accumulate into the caller's value).
- * 2.1 (2100): + ifl_cond_* (the conditioner of the affine coupling), ifl_adam_flat_f32; nothing else changes. */
+ * 2.1 (2100): + ifl_cond_* (the conditioner of the affine coupling), ifl_adam_flat_f32, ifl_rqspline_p_*; nothing else
+ *   changes (ifl_activation_workspace_bytes returns one row more). */
 int ifl_version(void);
 
 /* Message of the last failing call made by this thread ("" if none). */
@@ -323,6 +324,17 @@ int ifl_rqspline_f32(const float *x, const float *cw, const float *ch, const flo
 int ifl_rqspline_backward_f32(const float *gy, const float *g_logdet, const float *x, const float *cw, const float *ch,
                               const float *dv, int n_bins, float tail_bound, float *gx, float *g_tables, int B, int C, int H,
                               int W, void *ws, size_t ws_bytes, ifl_stream_t stream);
+
+/* The same spline straight from its parameters (unnormalized widths / heights: n_bins floats, derivatives: n_bins - 1): the
+ * knot tables are computed inside the launch -- one launch less each way than ifl_rqspline_tables_f32 + ifl_rqspline_f32 --
+ * and kept in `tables` (3 (n_bins + 1) floats: cw | ch | dv) for the backward, which returns the parameters' gradients.
+ * Same arithmetic, same bits as the two-call form. */
+int ifl_rqspline_p_f32(const float *x, const float *uw, const float *uh, const float *ud, int n_bins, float tail_bound, float *y,
+                       float *logdet, float *tables, int B, int C, int H, int W, int inverse, void *ws, size_t ws_bytes,
+                       ifl_stream_t stream);
+int ifl_rqspline_p_backward_f32(const float *gy, const float *g_logdet, const float *x, const float *tables, const float *uw,
+                                const float *uh, const float *ud, int n_bins, float tail_bound, float *gx, float *g_uw, float *g_uh,
+                                float *g_ud, int B, int C, int H, int W, void *ws, size_t ws_bytes, ifl_stream_t stream);
 
 /* SplineActivation with INDIVIDUAL weights (activations.py:135-144: one set of knots per element; parameters of shape
  * (1, C, H, W, n_bins) -- here P = C*H*W element positions, DEVICE arrays uw, uh of P*n_bins floats and ud of P*(n_bins-1)).

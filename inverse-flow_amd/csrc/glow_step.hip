@@ -689,19 +689,71 @@ template <class T> __device__ __forceinline__ void rq_eval(const T &x, const T &
 }
 __device__ __forceinline__ float flog(const float &a) { return __logf(a); }
 
+// Knot tables of the shared-weight spline from its parameters (rational_quadratic.py:35-46,97-116), by the first wave of a
+// workgroup (every thread of the workgroup must call: two barriers inside); lane i of each half-wave owns bin i of the
+// widths / heights, every sum is added by one lane in the serial order (see k_rq_tables below: the same bits).
+//   cw_j = 2T cum_j - T,  cum_j = sum_{i<j} (m + (1 - m K) softmax(uw)_i),  cw_0 = -T, cw_K = T   (ch likewise from uh)
+//   dv_j = m + softplus(ud_{j-1} + c) for 0 < j < K,  dv_0 = dv_K = m + softplus(c),  c = log(e^{1-m} - 1),  m = 1e-6
+__device__ __forceinline__ void rq_tables_compute(const float *__restrict__ uw, const float *__restrict__ uh, const float *__restrict__ ud,
+                                                  int K, float T, float *cw, float *ch, float *dv, float (*ex)[32])
+{
+    const bool w0 = threadIdx.x < 64;
+    const int which = (threadIdx.x >> 5) & 1, i = threadIdx.x & 31;
+    const float m = 1e-6f, c = logf(expf(1.0f - m) - 1.0f);
+    const float *u = which ? uh : uw;
+    float *out = which ? ch : cw;
+    float mx = 0.f;
+    if (w0) {
+        mx = u[0];
+        for (int t = 1; t < K; ++t) mx = fmaxf(mx, u[t]);
+        if (i < K) ex[which][i] = expf(u[i] - mx);
+    }
+    __syncthreads();
+    if (w0) {
+        float den = 0.f;
+        for (int t = 0; t < K; ++t) den += ex[which][t];
+        if (i < K) {
+            float cum = 0.f;
+            for (int t = 0; t <= i; ++t) cum += m + (1.0f - m * K) * (ex[which][t] / den);
+            out[i + 1] = i + 1 == K ? T : 2.0f * T * cum - T;
+        }
+        if (i == 0) out[0] = -T;
+        if (which == 0 && i <= K) {
+            const float a = (i == 0 || i == K) ? c : ud[i - 1] + c;
+            dv[i] = m + (fmaxf(a, 0.f) + log1pf(expf(-fabsf(a))));
+        }
+    }
+    __syncthreads();
+}
+
 template <int NB>
 __global__ __launch_bounds__(GS_T) void k_rqspline(const float *__restrict__ x, float *__restrict__ y,
                                                    float *__restrict__ partial, const float *__restrict__ cw,
                                                    const float *__restrict__ ch, const float *__restrict__ dv, int HW,
-                                                   float tail, int inverse)
+                                                   float tail, int inverse, const float *__restrict__ uw = nullptr,
+                                                   const float *__restrict__ uh = nullptr, const float *__restrict__ ud = nullptr,
+                                                   float *__restrict__ tables_out = nullptr)
 {
     __shared__ float sh[4];
-    RqTables t; // (wave-uniform loads: the tables live in scalar registers)
+    __shared__ float tb[3][RQ_MAXB + 1], ex[2][32];
+    RqTables t;
+    if (uw) { // from the parameters: every workgroup computes the tables itself (a launch less), the first one keeps them
+        rq_tables_compute(uw, uh, ud, NB, tail, tb[0], tb[1], tb[2], ex);
 #pragma unroll
-    for (int j = 0; j <= NB; ++j) {
-        t.cw[j] = cw[j];
-        t.ch[j] = ch[j];
-        t.dv[j] = dv[j];
+        for (int j = 0; j <= NB; ++j) {
+            t.cw[j] = tb[0][j];
+            t.ch[j] = tb[1][j];
+            t.dv[j] = tb[2][j];
+        }
+        if (tables_out && blockIdx.x == 0 && threadIdx.x < 3 * (NB + 1))
+            tables_out[threadIdx.x] = tb[threadIdx.x / (NB + 1)][threadIdx.x % (NB + 1)];
+    } else { // (wave-uniform loads: the tables live in scalar registers)
+#pragma unroll
+        for (int j = 0; j <= NB; ++j) {
+            t.cw[j] = cw[j];
+            t.ch[j] = ch[j];
+            t.dv[j] = dv[j];
+        }
     }
     const size_t plane = blockIdx.x;
     const float *xp = x + plane * HW;
@@ -830,59 +882,52 @@ __global__ __launch_bounds__(64) void k_rq_tables(const float *__restrict__ uw, 
 {
     __shared__ float ex[2][32];
     if (blockIdx.x != 0) return;
-    const int which = threadIdx.x >> 5, i = threadIdx.x & 31;
-    const float m = 1e-6f, c = logf(expf(1.0f - m) - 1.0f);
-    const float *u = which ? uh : uw;
-    float *out = which ? ch : cw;
-    float mx = u[0];
-    for (int t = 1; t < K; ++t) mx = fmaxf(mx, u[t]);
-    if (i < K) ex[which][i] = expf(u[i] - mx);
-    __syncthreads();
-    float den = 0.f;
-    for (int t = 0; t < K; ++t) den += ex[which][t];
-    if (i < K) {
-        float cum = 0.f;
-        for (int t = 0; t <= i; ++t) cum += m + (1.0f - m * K) * (ex[which][t] / den);
-        out[i + 1] = i + 1 == K ? T : 2.0f * T * cum - T;
-    }
-    if (i == 0) out[0] = -T;
-    if (which == 0 && i <= K) {
-        const float a = (i == 0 || i == K) ? c : ud[i - 1] + c;
-        dv[i] = m + (fmaxf(a, 0.f) + log1pf(expf(-fabsf(a))));
-    }
+    rq_tables_compute(uw, uh, ud, K, T, cw, ch, dv, ex);
 }
 // g_tables = (g_cw, g_ch, g_dv), 3 (K + 1) floats -> gradients of the parameters
+__device__ __forceinline__ void rq_tables_bwd_compute(const float *gt, const float *__restrict__ uw, const float *__restrict__ uh,
+                                                      const float *__restrict__ ud, float *__restrict__ guw, float *__restrict__ guh,
+                                                      float *__restrict__ gud, int K, float T, float (*pr)[32], float (*gv)[32])
+{ // (the first wave of a workgroup; every thread of it must call: two barriers inside)
+    const bool w0 = threadIdx.x < 64;
+    const int which = (threadIdx.x >> 5) & 1, i = threadIdx.x & 31;
+    const float m = 1e-6f, c = logf(expf(1.0f - m) - 1.0f);
+    const float *u = which ? uh : uw;
+    const float *g = gt + which * (K + 1);
+    float *out = which ? guh : guw;
+    if (w0) {
+        float mx = u[0];
+        for (int t = 1; t < K; ++t) mx = fmaxf(mx, u[t]);
+        if (i < K) pr[which][i] = expf(u[i] - mx);
+    }
+    __syncthreads();
+    float den = 0.f;
+    if (w0) {
+        for (int t = 0; t < K; ++t) den += pr[which][t];
+        // g_v_i = (1 - m K) 2T sum_{j = i+1}^{K-1} g_knot_j  (the end knots are constants; added from the last knot down)
+        if (i < K) {
+            float tail = 0.f;
+            for (int t = K - 1; t > i; --t) tail += g[t];
+            gv[which][i] = (1.0f - m * K) * 2.0f * T * tail;
+        }
+    }
+    __syncthreads();
+    if (w0) {
+        float dot = 0.f;
+        for (int t = 0; t < K; ++t) dot += (pr[which][t] / den) * gv[which][t];
+        if (i < K) out[i] = (pr[which][i] / den) * (gv[which][i] - dot);
+        const float *gd = gt + 2 * (K + 1);
+        if (which == 1 && i >= 1 && i < K) gud[i - 1] = gd[i] / (1.0f + expf(-(ud[i - 1] + c)));
+    }
+}
 __global__ __launch_bounds__(64) void k_rq_tables_bwd(const float *__restrict__ gt, const float *__restrict__ uw,
                                                       const float *__restrict__ uh, const float *__restrict__ ud, float *__restrict__ guw,
                                                       float *__restrict__ guh, float *__restrict__ gud, int K, float T)
 {
     __shared__ float pr[2][32], gv[2][32];
     if (blockIdx.x != 0) return;
-    const int which = threadIdx.x >> 5, i = threadIdx.x & 31;
-    const float m = 1e-6f, c = logf(expf(1.0f - m) - 1.0f);
-    const float *u = which ? uh : uw;
-    const float *g = gt + which * (K + 1);
-    float *out = which ? guh : guw;
-    float mx = u[0];
-    for (int t = 1; t < K; ++t) mx = fmaxf(mx, u[t]);
-    if (i < K) pr[which][i] = expf(u[i] - mx);
-    __syncthreads();
-    float den = 0.f;
-    for (int t = 0; t < K; ++t) den += pr[which][t];
-    // g_v_i = (1 - m K) 2T sum_{j = i+1}^{K-1} g_knot_j  (the end knots are constants; added from the last knot down)
-    if (i < K) {
-        float tail = 0.f;
-        for (int t = K - 1; t > i; --t) tail += g[t];
-        gv[which][i] = (1.0f - m * K) * 2.0f * T * tail;
-    }
-    __syncthreads();
-    float dot = 0.f;
-    for (int t = 0; t < K; ++t) dot += (pr[which][t] / den) * gv[which][t];
-    if (i < K) out[i] = (pr[which][i] / den) * (gv[which][i] - dot);
-    const float *gd = gt + 2 * (K + 1);
-    if (which == 1 && i >= 1 && i < K) gud[i - 1] = gd[i] / (1.0f + expf(-(ud[i - 1] + c)));
+    rq_tables_bwd_compute(gt, uw, uh, ud, guw, guh, gud, K, T, pr, gv);
 }
-
 
 // ---- the spline with one set of knots per element ("individual weights", activations.py:135-144: parameters of shape
 // (1, C, H, W, n_bins): the MNIST Glow's activation).  A thread owns one element position e of the P = C H W and a group of
@@ -1073,7 +1118,8 @@ extern "C" {
 size_t ifl_activation_workspace_bytes(int B, int C, int n_bins)
 {
     const size_t planes = (size_t)(B > 0 ? B : 0) * (C > 0 ? C : 0);
-    return planes * (3 * (size_t)(n_bins > 0 ? n_bins + 1 : 1) + 1) * sizeof(float) + 256;
+    const size_t row = 3 * (size_t)(n_bins > 0 ? n_bins + 1 : 1);
+    return (planes * (row + 1) + row) * sizeof(float) + 256; // (per-plane table partials, per-plane sums, one row of totals)
 }
 
 int ifl_slr_f32(const float *x, float *y, float *logdet, int B, int C, int H, int W, float alpha, int reverse, void *ws,
@@ -1186,6 +1232,73 @@ int ifl_rqspline_backward_f32(const float *gy, const float *g_logdet, const floa
 #undef IFL_RQ
     }
     hipLaunchKernelGGL(k_table_sums, dim3(3 * (n_bins + 1)), dim3(64), 0, s, tpart, g_tables, planes, 3 * (n_bins + 1));
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+
+/* the shared-weight spline straight from its parameters: the tables are computed inside the launch (and kept in `tables`:
+ * 3 (n_bins + 1) floats, for the backward); one launch less each way than tables + spline */
+int ifl_rqspline_p_f32(const float *x, const float *uw, const float *uh, const float *ud, int n_bins, float tail_bound, float *y,
+                       float *logdet, float *tables, int B, int C, int H, int W, int inverse, void *ws, size_t ws_bytes,
+                       ifl_stream_t stream)
+{
+    clear_error();
+    if (int rc = check_dims("ifl_rqspline_p_f32", B, C, H, W)) return rc;
+    if (n_bins < 1 || n_bins > RQ_MAXB) IFL_FAIL(IFL_EUNSUPPORTED, "ifl_rqspline_p_f32: n_bins=%d (1..%d supported)", n_bins, RQ_MAXB);
+    if (!uw || !uh || (!ud && n_bins > 1)) IFL_FAIL(IFL_EINVAL, "ifl_rqspline_p_f32: null pointer");
+    if (B == 0) return IFL_OK;
+    if (!x || !y) IFL_FAIL(IFL_EINVAL, "ifl_rqspline_p_f32: null pointer");
+    if (logdet && (!ws || ws_bytes < ifl_activation_workspace_bytes(B, C, 0)))
+        IFL_FAIL(IFL_EWORKSPACE, "ifl_rqspline_p_f32: workspace of %zu bytes needed", ifl_activation_workspace_bytes(B, C, 0));
+    hipStream_t s = (hipStream_t)stream;
+    float *partial = logdet ? (float *)(((uintptr_t)ws + 255) & ~(uintptr_t)255) : nullptr;
+    const dim3 grid((unsigned)((size_t)B * C));
+#define IFL_RQ(NB)                                                                                                              \
+    case NB:                                                                                                                    \
+        hipLaunchKernelGGL(k_rqspline<NB>, grid, dim3(GS_T), 0, s, x, y, partial, (const float *)nullptr, (const float *)nullptr, \
+                           (const float *)nullptr, H * W, tail_bound, inverse, uw, uh, ud, tables);                             \
+        break;
+    switch (n_bins) {
+        IFL_RQ(1) IFL_RQ(2) IFL_RQ(3) IFL_RQ(4) IFL_RQ(5) IFL_RQ(6) IFL_RQ(7) IFL_RQ(8)
+        IFL_RQ(9) IFL_RQ(10) IFL_RQ(11) IFL_RQ(12) IFL_RQ(13) IFL_RQ(14) IFL_RQ(15) IFL_RQ(16)
+    }
+#undef IFL_RQ
+    if (logdet) hipLaunchKernelGGL(k_plane_sums, dim3((B + 63) / 64), dim3(64), 0, s, partial, logdet, B, C);
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+
+/* its backward: gx and the gradients of the three parameter vectors (tables: what the forward kept) */
+int ifl_rqspline_p_backward_f32(const float *gy, const float *g_logdet, const float *x, const float *tables, const float *uw,
+                                const float *uh, const float *ud, int n_bins, float tail_bound, float *gx, float *g_uw, float *g_uh,
+                                float *g_ud, int B, int C, int H, int W, void *ws, size_t ws_bytes, ifl_stream_t stream)
+{
+    clear_error();
+    if (int rc = check_dims("ifl_rqspline_p_backward_f32", B, C, H, W)) return rc;
+    if (n_bins < 1 || n_bins > RQ_MAXB) IFL_FAIL(IFL_EUNSUPPORTED, "ifl_rqspline_p_backward_f32: n_bins=%d (1..%d supported)", n_bins, RQ_MAXB);
+    if (!gy || !x || !gx || !tables || !uw || !uh || (!ud && n_bins > 1) || !g_uw || !g_uh || (!g_ud && n_bins > 1))
+        IFL_FAIL(IFL_EINVAL, "ifl_rqspline_p_backward_f32: null pointer");
+    if (!ws || ws_bytes < ifl_activation_workspace_bytes(B, C, n_bins))
+        IFL_FAIL(IFL_EWORKSPACE, "ifl_rqspline_p_backward_f32: workspace of %zu bytes needed", ifl_activation_workspace_bytes(B, C, n_bins));
+    hipStream_t s = (hipStream_t)stream;
+    float *tpart = (float *)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    const size_t planes = (size_t)B * C;
+    const float *cw = tables, *ch = tables + (n_bins + 1), *dv = tables + 2 * (n_bins + 1);
+    if (planes) {
+        const dim3 grid((unsigned)planes);
+#define IFL_RQ(NB) \
+    case NB: hipLaunchKernelGGL(k_rqspline_bwd<NB>, grid, dim3(GS_T), 0, s, gy, g_logdet, x, gx, tpart, cw, ch, dv, C, H * W, tail_bound); break;
+        switch (n_bins) {
+            IFL_RQ(1) IFL_RQ(2) IFL_RQ(3) IFL_RQ(4) IFL_RQ(5) IFL_RQ(6) IFL_RQ(7) IFL_RQ(8)
+            IFL_RQ(9) IFL_RQ(10) IFL_RQ(11) IFL_RQ(12) IFL_RQ(13) IFL_RQ(14) IFL_RQ(15) IFL_RQ(16)
+        }
+#undef IFL_RQ
+    }
+    // (the table sums and their chain to the parameters stay two launches: merged into one workgroup they took 11 us against
+    // 4.8 + 4.7)
+    float *gt = tpart + planes * 3 * (n_bins + 1); // (the workspace's row of totals)
+    hipLaunchKernelGGL(k_table_sums, dim3(3 * (n_bins + 1)), dim3(64), 0, s, tpart, gt, planes, 3 * (n_bins + 1));
+    hipLaunchKernelGGL(k_rq_tables_bwd, dim3(1), dim3(64), 0, s, (const float *)gt, uw, uh, ud, g_uw, g_uh, g_ud, n_bins, tail_bound);
     IFL_HIP(hipGetLastError());
     return IFL_OK;
 }

@@ -168,6 +168,28 @@ class _SplineFn(torch.autograd.Function):
         return gx, gcw, gch, gdv, None
 
 
+class _SplineParamFn(torch.autograd.Function):
+    """the shared-weight spline from its parameters in one launch each way (ifl_rqspline_p_f32 / _backward_f32: the knot tables
+    are computed inside the spline's launch, their gradients chained to the parameters inside the reduction's) -- what
+    _TablesFn + _SplineFn do in two"""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, x, uw, uh, ud, tail_bound):
+        x, uw, uh, ud = x.contiguous(), uw.contiguous(), uh.contiguous(), ud.contiguous()
+        y, ld, tables = H.rqspline_p(x, uw, uh, ud, tail_bound)
+        ctx.save_for_backward(x, tables, uw, uh, ud)
+        ctx.tail_bound = tail_bound
+        return y, ld
+
+    @staticmethod
+    @_bwd32
+    def backward(ctx, gy, gld):
+        x, tables, uw, uh, ud = ctx.saved_tensors
+        return (*H.rqspline_p_backward(gy.contiguous(), None if gld is None else gld.contiguous(), x, tables, uw, uh, ud,
+                                       ctx.tail_bound), None)
+
+
 class _SplinePEFn(torch.autograd.Function):
     """the spline with per-element knots: one kernel forward (tables built in registers), one backward + a fixed-order sum
     of the parameter gradients over image groups (ifl_rqspline_pe_f32 / _backward_f32)"""
@@ -220,6 +242,11 @@ class SplineActivation(FlowActivationLayer):
     def forward(self, input, context=None):
         return self.activation_and_logdet(input, context)
 
+    def _from_params(self, input):
+        p = self.unnormalized_widths
+        return (input.dtype == torch.float32 and p.is_cuda and p.dtype == torch.float32 and 2 <= self.n_bins <= 16
+                and not os.environ.get("IFL_TORCH_SPLINE_TABLES"))
+
     def _hip_pe(self, input):
         return (_hip_ok(input) and self.individual_weights and 1 <= self.n_bins <= 8
                 and tuple(input.shape[1:]) == tuple(self.unnormalized_widths.shape[1:-1]))
@@ -229,6 +256,9 @@ class SplineActivation(FlowActivationLayer):
             return _SplinePEFn.apply(input, self.unnormalized_widths, self.unnormalized_heights, self.unnormalized_derivatives,
                                      float(self.tail_bound))
         if self._hip(input):
+            if self._from_params(input):
+                return _SplineParamFn.apply(input, self.unnormalized_widths, self.unnormalized_heights,
+                                            self.unnormalized_derivatives, float(self.tail_bound))
             cw, ch, dv = self._tables()
             return _SplineFn.apply(input, cw, ch, dv, float(self.tail_bound))
         return _spline_torch(self, input, inverse=False)
@@ -238,6 +268,10 @@ class SplineActivation(FlowActivationLayer):
             return H.rqspline_pe(input.contiguous(), self.unnormalized_widths.contiguous(), self.unnormalized_heights.contiguous(),
                                  self.unnormalized_derivatives.contiguous(), float(self.tail_bound), inverse=True, want_logdet=False)[0]
         if self._hip(input) and input.dtype == torch.float32 and not torch.is_grad_enabled():
+            if self._from_params(input):
+                return H.rqspline_p(input.contiguous(), self.unnormalized_widths.contiguous(), self.unnormalized_heights.contiguous(),
+                                    self.unnormalized_derivatives.contiguous(), float(self.tail_bound), inverse=True,
+                                    want_logdet=False)[0]
             cw, ch, dv = self._tables()
             return H.rqspline(input.contiguous(), cw, ch, dv, float(self.tail_bound), inverse=True, want_logdet=False)[0]
         return _spline_torch(self, input, inverse=True)[0]

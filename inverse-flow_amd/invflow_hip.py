@@ -77,6 +77,8 @@ SIGNATURES = {
     "ifl_rqspline_tables_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     "ifl_rqspline_f32": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ifl_rqspline_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "ifl_rqspline_p_f32": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "ifl_rqspline_p_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ifl_rqspline_pe_workspace_bytes": (_sz, [_i, _i, _i]),
     "ifl_rqspline_pe_f32": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "ifl_rqspline_pe_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _i, _vp, _sz, _vp]),
@@ -752,6 +754,44 @@ def rqspline_backward(gy, g_logdet, x, cw, ch, dv, tail_bound):
     _check(rc, "ifl_rqspline_backward_f32")
     gt = gt.view(3, nbins + 1)
     return gx, gt[0], gt[1], gt[2]
+
+
+def rqspline_p(x, uw, uh, ud, tail_bound, inverse=False, want_logdet=True):
+    """the shared-weight spline from its parameters, tables computed in the launch: (y, logdet, tables)"""
+    B, C, H, W = _chk4(x, "input")
+    for t, n in ((uw, "unnormalized_widths"), (uh, "unnormalized_heights"), (ud, "unnormalized_derivatives")):
+        _chk_tensor(t, n)
+    nbins = uw.numel()
+    if uh.numel() != nbins or ud.numel() != nbins - 1:
+        raise RuntimeError("spline parameters: n_bins widths, n_bins heights, n_bins - 1 derivatives")
+    dev = _same_device(x, uw, uh, ud)
+    y = torch.empty_like(x)
+    ld = torch.empty(B, dtype=torch.float32, device=dev) if want_logdet else None
+    tables = torch.empty(3 * (nbins + 1), dtype=torch.float32, device=dev)
+    with _on(dev):
+        ws, nb = _act_ws(B, C, 0, dev)
+        rc = lib().ifl_rqspline_p_f32(_ptr(x), _ptr(uw), _ptr(uh), _ptr(ud), nbins, float(tail_bound), _ptr(y), _ptr(ld), _ptr(tables),
+                                      B, C, H, W, 1 if inverse else 0, _ptr(ws), nb, _stream())
+    _check(rc, "ifl_rqspline_p_f32")
+    return y, ld, tables
+
+
+def rqspline_p_backward(gy, g_logdet, x, tables, uw, uh, ud, tail_bound):
+    """(gx, g_uw, g_uh, g_ud) of the forward direction"""
+    B, C, H, W = _chk4(x, "input")
+    _chk_tensor(gy, "grad_output")
+    _chk_tensor(tables, "tables")
+    nbins = uw.numel()
+    dev = _same_device(x, gy, tables, uw, uh, ud)
+    gx = torch.empty_like(x)
+    guw, guh, gud = torch.empty_like(uw), torch.empty_like(uh), torch.empty_like(ud)
+    with _on(dev):
+        ws, nb = _act_ws(B, C, nbins, dev)
+        rc = lib().ifl_rqspline_p_backward_f32(_ptr(gy), _ptr(g_logdet), _ptr(x), _ptr(tables), _ptr(uw), _ptr(uh), _ptr(ud), nbins,
+                                               float(tail_bound), _ptr(gx), _ptr(guw), _ptr(guh), _ptr(gud), B, C, H, W, _ptr(ws), nb,
+                                               _stream())
+    _check(rc, "ifl_rqspline_p_backward_f32")
+    return gx, guw, guh, gud
 
 
 def _pe_params(x, uw, uh, ud):

@@ -377,3 +377,32 @@ def test_spline_tables_kernels(H, oracle):
         guw, guh, gud = H.rqspline_tables_backward(dev(gt), dev(uw), dev(uh), dev(ud), tb)
         assert rel_err(host(guw), tw.grad.numpy()) < TOL and rel_err(host(guh), th.grad.numpy()) < TOL
         assert rel_err(host(gud), td.grad.numpy()) < TOL
+
+
+@pytest.mark.parametrize("nb,tb,shape", [(10, 20.0, (3, 12, 16, 16)), (5, 10.0, (2, 24, 8, 8)), (16, 3.0, (1, 4, 5, 7)), (2, 1.0, (4, 2, 3, 3))])
+def test_spline_from_parameters_is_the_two_call_form_bit_for_bit(H, nb, tb, shape):
+    """ifl_rqspline_p_f32 / _backward_f32 (knot tables computed inside the spline's launch, their gradients chained to the
+    parameters inside the reduction's launch) against tables + spline as two calls each way: the same arithmetic in the same
+    order -- values, log-det, inverse, input gradient and the three parameter gradients identical in every bit."""
+    from inf.layers.activations import _SplineFn, _SplineParamFn, _TablesFn
+    torch.manual_seed(nb)
+    x = (torch.randn(shape) * 0.6 * tb).cuda()
+    gy, gld = torch.randn(shape).cuda(), torch.randn(shape[0]).cuda()
+    ps = [torch.randn(nb).cuda().requires_grad_(), torch.randn(nb).cuda().requires_grad_(), torch.randn(nb - 1).cuda().requires_grad_()]
+    outs = []
+    for merged in (True, False):
+        for p in ps:
+            p.grad = None
+        xg = x.clone().requires_grad_()
+        if merged:
+            y, ld = _SplineParamFn.apply(xg, *ps, tb)
+        else:
+            y, ld = _SplineFn.apply(xg, *_TablesFn.apply(*ps, tb), tb)
+        ((y * gy).sum() + (ld * gld).sum()).backward()
+        outs.append([y.detach(), ld.detach(), xg.grad] + [p.grad.clone() for p in ps])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    back = H.rqspline_p(outs[0][0].contiguous(), *[p.detach() for p in ps], tb, inverse=True, want_logdet=False)[0]
+    cw, ch, dv = H.rqspline_tables(*[p.detach() for p in ps], tb)
+    assert torch.equal(back, H.rqspline(outs[0][0].contiguous(), cw, ch, dv, tb, inverse=True, want_logdet=False)[0])
+

@@ -740,37 +740,38 @@ __global__ __launch_bounds__(64) void k_cond_wgrad(WJobs jobs, float *__restrict
     }
 }
 
-// out[i] = sum_s gpart[s][i] (i < per_slice: dW1 | dW2 | dW3), out[per_slice + c] = sum_tiles tpart[tile][c] (c < 2C: d logs | d b3)
+// out[i] = sum_s gpart[s][i] (i < per_slice: dW1 | dW2 | dW3), out[per_slice + c] = sum_tiles tpart[tile][c] (c < 2C: d logs | d b3).
+// Eight lanes per output: lane k adds the slices k, k + 8, ... in order, the eight partial sums meet in a fixed shuffle tree
+// (with one thread per output the launch is a few dozen workgroups each walking 40 dependent loads: 15 us at the configs[2]
+// shapes).
 __global__ __launch_bounds__(256) void k_cond_wreduce(const float *__restrict__ gpart, const float *__restrict__ tpart,
                                                       float *__restrict__ out, size_t per_slice, int S, int tiles, int C2)
 {
-    const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+    const size_t gid = blockIdx.x * (size_t)256 + threadIdx.x, i = gid >> 3;
+    const int part = (int)(gid & 7);
+    float t = 0.f;
     if (i < per_slice) {
-        float t = 0.f;
-        int sl = 0;
-        for (; sl + 8 <= S; sl += 8) { // (eight loads in flight, added in slice order)
-            float v[8];
+        for (int sl = part; sl < S; sl += 32) { // (up to four loads in flight)
+            float v[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = gpart[(size_t)(sl + k) * per_slice + i];
+            for (int k = 0; k < 4; ++k) v[k] = sl + 8 * k < S ? gpart[(size_t)(sl + 8 * k) * per_slice + i] : 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) t += v[k];
+            for (int k = 0; k < 4; ++k) t += v[k];
         }
-        for (; sl < S; ++sl) t += gpart[(size_t)sl * per_slice + i];
-        out[i] = t;
     } else if (i < per_slice + C2) {
         const int c = (int)(i - per_slice);
-        float t = 0.f;
-        int k = 0;
-        for (; k + 8 <= tiles; k += 8) {
-            float v[8];
+        for (int k0 = part; k0 < tiles; k0 += 32) {
+            float v[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = tpart[(size_t)(k + j) * C2 + c];
+            for (int k = 0; k < 4; ++k) v[k] = k0 + 8 * k < tiles ? tpart[(size_t)(k0 + 8 * k) * C2 + c] : 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t += v[j];
+            for (int k = 0; k < 4; ++k) t += v[k];
         }
-        for (; k < tiles; ++k) t += tpart[(size_t)k * C2 + c];
-        out[i] = t;
     }
+    t += __shfl_down(t, 4, 64);
+    t += __shfl_down(t, 2, 64);
+    t += __shfl_down(t, 1, 64);
+    if (part == 0 && i < per_slice + C2) out[i] = t;
 }
 
 // workspace of the backward (byte offsets, 256-aligned): operand matrices | u | per-tile sums | per-slice partial gradients
@@ -847,7 +848,7 @@ template <int C> struct CondLaunch {
         jobs.j[2] = WJob{g3t, p3t, C, 9 * C, nt3, mt1 * nt1 + mt23 * nt2, (size_t)s.Wd * K1 + (size_t)C * s.Wd};
         const int ntiles = mt1 * nt1 + mt23 * nt2 + mt23 * nt3, S = (P + WSL - 1) / WSL;
         hipLaunchKernelGGL(k_cond_wgrad<T>, dim3(ntiles * S), dim3(64), 0, st, jobs, gpart, P, S, w.per_slice);
-        hipLaunchKernelGGL(k_cond_wreduce, dim3((unsigned)((w.per_slice + 2 * C + 255) / 256)), dim3(256), 0, st, (const float *)gpart,
+        hipLaunchKernelGGL(k_cond_wreduce, dim3((unsigned)((8 * (w.per_slice + 2 * C) + 255) / 256)), dim3(256), 0, st, (const float *)gpart,
                            (const float *)tpart, grads, w.per_slice, S, tiles, 2 * C);
         IFL_HIP(hipGetLastError());
         return IFL_OK;

@@ -379,7 +379,8 @@ def test_spline_tables_kernels(H, oracle):
         assert rel_err(host(gud), td.grad.numpy()) < TOL
 
 
-@pytest.mark.parametrize("nb,tb,shape", [(10, 20.0, (3, 12, 16, 16)), (5, 10.0, (2, 24, 8, 8)), (16, 3.0, (1, 4, 5, 7)), (2, 1.0, (4, 2, 3, 3))])
+@pytest.mark.parametrize("nb,tb,shape", [(10, 20.0, (3, 12, 16, 16)), (5, 10.0, (2, 24, 8, 8)), (16, 3.0, (1, 4, 5, 7)), (2, 1.0, (4, 2, 3, 3)),
+                                         (7, 6.0, (2, 40, 32, 32))])
 def test_spline_from_parameters_is_the_two_call_form_bit_for_bit(H, nb, tb, shape):
     """ifl_rqspline_p_f32 / _backward_f32 (knot tables computed inside the spline's launch, their gradients chained to the
     parameters inside the reduction's launch) against tables + spline as two calls each way: the same arithmetic in the same

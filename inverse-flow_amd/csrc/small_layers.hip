@@ -237,6 +237,63 @@ __global__ __launch_bounds__(256) void k_wgrad_batchpar(const float *__restrict_
     }
 }
 
+// The same sums on the matrix pipe for the layers with 12 and more channels (the CIFAR / ImageNet-32 levels: C = 12, 24,
+// 48): per image part a GEMM  partial[co][(ci, t)] = sum_p gz[co][p] * x[ci][p + tap t]  with M = C, N = C KH KW and the
+// pixels as the reduction index, on v_mfma_f32_16x16x4_f32 -- fp32 products and sums, as the FMA form, at two LDS words a
+// lane per 1024 multiply-adds where the FMA form reads ten per 576: 16.1 -> 11.1 us a launch at (32, 12, 16, 16),
+// 12.9 -> 11.0 at (32, 24, 8, 8), 19.2 -> 17.6 at (32, 48, 4, 4) (what remains is staging and the slab's stores; four
+// independent sums with a leaner staging pass measured the same within 1 us either way).  Staging as above; the pitch of a gz plane is 4 (mod 8) words, so that the 16 rows x 4 pixels of an A
+// fragment fall into 64 different banks.  A wave owns output tiles (16 co x 16 (ci, t)); a reduction step is four
+// consecutive pixels of an image row (lane / 16 picks the pixel; columns past W contribute zeros).
+__host__ __device__ inline int wgrad_mma_pitch(int HW) { return HW + ((4 - HW) & 7); }
+
+typedef float wg_f4 __attribute__((ext_vector_type(4)));
+
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void k_wgrad_batchmma(const float *__restrict__ gz, const float *__restrict__ x,
+                                                        float *__restrict__ partial, int C, int H, int W, int pt, int pl,
+                                                        int nsplit)
+{
+    extern __shared__ float smem[];
+    constexpr int NT = KH * KW;
+    const int HW = H * W, PG = wgrad_mma_pitch(HW), WH = W + KW - 1, HH = H + KH - 1, PX = (HH * WH) | 1;
+    float *gs = smem, *xs = smem + C * PG;
+    const int b = blockIdx.x / nsplit, part = blockIdx.x % nsplit, tid = threadIdx.x;
+    const int r0 = part * H / nsplit, r1 = (part + 1) * H / nsplit;
+    for (int i = tid; i < C * PX; i += 256) xs[i] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < C * HW; i += 256) {
+        const int c = i / HW, r = i % HW, h = r / W, w = r % W;
+        gs[c * PG + r] = gz[(size_t)b * C * HW + i];
+        xs[c * PX + (h + pt) * WH + (w + pl)] = x[(size_t)b * C * HW + i];
+    }
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6, m = lane & 15, kq = lane >> 4;
+    const int N = C * NT, NTL = (N + 15) / 16, tiles = ((C + 15) / 16) * NTL;
+    float *out = partial + (size_t)blockIdx.x * C * N;
+    for (int tile = wv; tile < tiles; tile += 4) {
+        const int mt = tile / NTL, nt = tile % NTL;
+        const int co = 16 * mt + m, n = 16 * nt + m;
+        const bool aok = co < C, bok = n < N;
+        const int nn = bok ? n : 0, ci = nn / NT, t = nn % NT;
+        const float *gp = gs + (aok ? co : 0) * PG;
+        const float *xp = xs + ci * PX + (t / KW) * WH + (t % KW);
+        wg_f4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int oh = r0; oh < r1; ++oh)
+            for (int ow0 = 0; ow0 < W; ow0 += 4) {
+                const int ow = ow0 + kq;
+                const bool ok = ow < W;
+                const float av = gp[oh * W + (ok ? ow : 0)], bv = xp[oh * WH + (ok ? ow : 0)];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aok && ok ? av : 0.f, bok && ok ? bv : 0.f, acc, 0, 0, 0);
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mt + 4 * kq + r;
+            if (row < C && bok) out[(size_t)row * N + n] = acc[r];
+        }
+    }
+}
+
 // dw[o] = scale * sum_b partial[b][o], masked like k_wgrad_direct.  64 outputs per workgroup; the images are summed in
 // four interleaved sequences (b = s, s+4, ...), combined as (s0 + s1) + (s2 + s3): a fixed order, deterministic.
 __global__ __launch_bounds__(256) void k_wgrad_batchred(const float *__restrict__ partial, float *__restrict__ dw, int B,
@@ -266,8 +323,10 @@ __global__ __launch_bounds__(256) void k_wgrad_batchred(const float *__restrict_
 // (room for two slabs per image: small batches split an image's rows over two workgroups)
 size_t wgrad_small_workspace_bytes(int B, int C, int KH, int KW) { return (size_t)2 * B * C * C * KH * KW * sizeof(float) + 256; }
 
+static bool wgrad_small_mma(int C) { return C >= 12; }
 static size_t wgrad_small_lds_bytes(int C, int H, int W, int KH, int KW)
 {
+    if (wgrad_small_mma(C)) return (size_t)C * (wgrad_mma_pitch(H * W) + (((H + KH - 1) * (W + KW - 1)) | 1)) * sizeof(float);
     const size_t red = C * C < 256 ? (size_t)256 * KH * KW : 0; // segment sums of the layers with few (co, ci) pairs
     return ((size_t)C * (((H * W) | 1) + (((H + KH - 1) * (W + KW - 1)) | 1)) + red) * sizeof(float);
 }
@@ -287,7 +346,12 @@ int launch_wgrad_small(const float *gz, const float *x, float *dw, void *ws, int
     float *partial = (float *)ws;
     const size_t lds = wgrad_small_lds_bytes(C, H, W, KH, KW);
     const int nsplit = (B <= 128 && H >= 8) ? 2 : 1; // (batches that leave half the compute units idle)
-    if (KH == 2)
+    if (wgrad_small_mma(C)) {
+        if (KH == 2)
+            hipLaunchKernelGGL((k_wgrad_batchmma<2, 2>), dim3(B * nsplit), dim3(256), lds, s, gz, x, partial, C, H, W, pt, pl, nsplit);
+        else
+            hipLaunchKernelGGL((k_wgrad_batchmma<3, 3>), dim3(B * nsplit), dim3(256), lds, s, gz, x, partial, C, H, W, pt, pl, nsplit);
+    } else if (KH == 2)
         hipLaunchKernelGGL((k_wgrad_batchpar<2, 2>), dim3(B * nsplit), dim3(256), lds, s, gz, x, partial, C, H, W, pt, pl, nsplit);
     else
         hipLaunchKernelGGL((k_wgrad_batchpar<3, 3>), dim3(B * nsplit), dim3(256), lds, s, gz, x, partial, C, H, W, pt, pl, nsplit);

@@ -107,6 +107,9 @@ CASES = [
     (2, 12, 16, 16, 3, 3, "0.05", "TR", 0),  # if_glow_cifar channel counts 12/24/48
     (2, 24, 8, 8, 3, 3, "0.05", "BL", 0),
     (3, 48, 8, 8, 3, 3, "0.03", "TL", 0),
+    (2, 48, 4, 4, 3, 3, "0.03", "TR", 0),
+    (3, 14, 7, 7, 2, 2, "0.05", "BL", 0),  # the small layers' MFMA weight gradient: rows that are no multiple of four pixels,
+    (2, 13, 10, 6, 3, 3, "0.05", "BR", 1),  # channel counts that are no multiple of the tile
     (64, 1, 28, 28, 3, 3, "refinit", "TL", 0),  # config 1: if_cnn_mnist 28x28x1, batch 64
     (5, 4, 14, 14, 2, 2, "0.05", "TL", 0),  # config 3: if_glow_mnist 2x2 kernels after squeeze
     (5, 8, 7, 7, 2, 2, "0.05", "TL", 0),

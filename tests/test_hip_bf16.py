@@ -88,19 +88,39 @@ def test_recon_term_in_bf16_storage(H):
     assert abs(float(rl16) - float(rl32)) <= 1e-5 * abs(float(rl32))
 
 
-def test_inverse_against_the_oracle_within_half_an_ulp(H, oracle):
-    B, C, HH, WW, K = 2, 16, 12, 12, 3
+ORACLE_SHAPES = [(2, 16, 12, 12, 3, "TL"), (2, 64, 32, 32, 3, "BR"), (2, 32, 16, 16, 2, "TR"), (1, 256, 8, 8, 3, "BL"),
+                 (3, 4, 14, 14, 2, "TL"), (2, 12, 16, 16, 3, "TR"), (2, 7, 5, 9, 3, "BR")]
+
+
+@pytest.mark.parametrize("B,C,HH,WW,K,order", ORACLE_SHAPES, ids=lambda v: str(v))
+def test_against_the_oracle_within_half_an_ulp(H, oracle, B, C, HH, WW, K, order):
+    """bf16 storage against the fp64 oracle itself (not against the f32 entry points), one shape per kernel family -- the
+    two-workgroup MFMA scan, the whole-image MFMA scan with padded channels, the LDS-resident small layers, the wide team
+    scan, the general kernel -- in every orientation: z, dx within half an ulp of bf16 plus the f32 path's 1e-5, dW (fp32
+    storage) at the f32 path's tolerance on the widened operands."""
     torch.manual_seed(5)
-    w = layer_weights(C, K, 2)
+    w = layer_weights(C, K, 2, scale=0.05 if C <= 16 else (0.02 if C <= 64 else 0.01))  # (well-conditioned: |z| stays O(|x|))
     x = torch.randn(B, C, HH, WW, device="cuda").to(BF)
-    z = H.inverse(x, w, "TL")
-    z_o = oracle.inverse(x.float().cpu().numpy().astype(np.float64), w.cpu().numpy().astype(np.float64), order="TL")
-    err = np.abs(z.float().cpu().numpy() - z_o)
-    # half an ulp of bf16 (8 significant bits: at most 2^-8 relative) plus the f32 path's own 1e-5
-    assert np.all(err <= 2.0 ** -8 * np.abs(z_o) * (1 + 1e-3) + 1e-5 * np.abs(z_o).max())
-    # and the round trip through the layer's reverse returns x to bf16 accuracy
-    xh = H.forward(z, w, "TL")
-    assert rel_err(xh.float().cpu().numpy(), x.float().cpu().numpy()) < 2.0 ** -7
+    g = torch.randn(B, C, HH, WW, device="cuda").to(BF)
+    w64 = w.cpu().numpy().astype(np.float64)
+    z = H.inverse(x, w, order)
+    z_o = oracle.inverse(x.float().cpu().numpy().astype(np.float64), w64, order=order)
+    half_ulp = lambda ref: 2.0 ** -8 * np.abs(ref) * (1 + 1e-3) + 1e-5 * np.abs(ref).max()
+    assert np.all(np.abs(z.float().cpu().numpy() - z_o) <= half_ulp(z_o))
+    # the backward of the STORED z (what the next call sees), against the oracle on the same widened operands
+    zs = z.float().cpu().numpy().astype(np.float64)
+    dx, dw, _ = H.backward(g, z, w, order)
+    dx_o = oracle.dy(g.float().cpu().numpy().astype(np.float64), w64, order=order)
+    dw_o = oracle.dw(zs, dx_o, (K, K), order=order)
+    assert np.all(np.abs(dx.float().cpu().numpy() - dx_o) <= half_ulp(dx_o))
+    assert dw.dtype == torch.float32 and rel_err(dw.cpu().numpy(), dw_o) < 3e-5
+    # the layer's reverse (x^ = A z) of the stored z, against the oracle's product of the same z
+    xh = H.forward(z, w, order)
+    xh_o = oracle.forward(zs, w64, order=order)
+    # (x^ is a sum of terms of the size of |z|: the f32 path's 1e-5 is relative to those)
+    slack = 2.0 ** -8 * np.abs(xh_o) * (1 + 1e-3) + 1e-5 * max(np.abs(xh_o).max(), np.abs(zs).max())
+    excess = np.abs(xh.float().cpu().numpy() - xh_o) - slack
+    assert excess.max() <= 0, (excess.max(), np.abs(xh_o).max(), np.abs(zs).max())
 
 
 def test_workspace_and_argument_checks(H):

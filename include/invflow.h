@@ -278,6 +278,19 @@ size_t ifl_cond_weights_floats(int C, int width);
 int ifl_cond_pixels_padded(int B, int H, int W);
 int ifl_cond_prep_f32(const float *w1, const float *w2, const float *w3, const float *logs, float *wt, int C, int width,
                       float logscale_factor, ifl_stream_t stream);
+
+/* The same for the couplings of a whole model in ONE launch: `jobs` is a DEVICE array of n_jobs entries (the pointers of
+ * an entry as for ifl_cond_prep_f32; every (C, width) must pass ifl_cond_supported -- the caller checks, the kernel
+ * cannot), max_weights_floats = the largest ifl_cond_weights_floats among them.  A training step calls it once before its
+ * forward pass; the table is built once (the parameters' addresses do not move). */
+typedef struct ifl_cond_prep_job {
+    const float *w1, *w2, *w3, *logs;
+    float *wt;
+    int C, width;
+    float logscale_factor;
+    int reserved;
+} ifl_cond_prep_job;
+int ifl_cond_prep_many_f32(const ifl_cond_prep_job *jobs, int n_jobs, size_t max_weights_floats, ifl_stream_t stream);
 int ifl_cond_forward_f32(const float *x, int x_channels, const float *wt, const float *w1, const float *w2, const float *b3, float *a2,
                          float *h, int B, int C, int H, int W, int width, ifl_stream_t stream);
 size_t ifl_cond_backward_workspace_bytes(int B, int C, int H, int W, int width, int operands_f32);

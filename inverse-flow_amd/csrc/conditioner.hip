@@ -109,6 +109,44 @@ __global__ __launch_bounds__(256) void k_cond_prep(const float *__restrict__ w1,
     }
 }
 
+// the same for many couplings in one launch (blockIdx.y = job): a training step prepares the weight images of all its
+// couplings up front instead of once per layer inside the forward -- 30 (configs[3]) to 144 (configs[4]) launches fewer a step
+struct PrepJob { // = ifl_cond_prep_job (include/invflow.h)
+    const float *w1, *w2, *w3, *logs;
+    float *wt;
+    int C, Wd;
+    float logscale;
+    int pad;
+};
+static_assert(sizeof(PrepJob) == 56, "ifl_cond_prep_job layout");
+__global__ __launch_bounds__(256) void k_cond_prep_many(const PrepJob *__restrict__ jobs)
+{
+    const PrepJob j = jobs[blockIdx.y];
+    const float *w1 = j.w1, *w2 = j.w2, *w3 = j.w3, *logs = j.logs;
+    const int C = j.C, Wd = j.Wd, K1 = 9 * (C / 2);
+    const size_t n1 = (size_t)K1 * Wd, n2 = (size_t)Wd * C, n3 = (size_t)9 * C * C;
+    const size_t total = n1 + n2 + 2 * n3 + C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float v; // (the cases of k_cond_prep)
+        if (i < n1) {
+            v = w1[(size_t)(i % Wd) * K1 + i / Wd];
+        } else if (i < n1 + n2) {
+            const size_t q = i - n1;
+            v = w2[(size_t)(q % C) * Wd + q / C];
+        } else if (i < n1 + n2 + n3) {
+            const size_t q = i - n1 - n2;
+            v = w3[(size_t)(q % C) * 9 * C + q / C];
+        } else if (i < n1 + n2 + 2 * n3) {
+            const size_t q = i - n1 - n2 - n3;
+            const int r = (int)(q / C), ci = (int)(q % C), co = r / 9, tap = r % 9;
+            v = w3[((size_t)co * C + ci) * 9 + tap];
+        } else {
+            v = expf(logs[i - n1 - n2 - 2 * n3] * j.logscale);
+        }
+        j.wt[i] = v;
+    }
+}
+
 // pixel of this lane
 struct Pix {
     int p, b, r, y, x;
@@ -899,6 +937,20 @@ int ifl_cond_prep_f32(const float *w1, const float *w2, const float *w3, const f
     const size_t n = cond_wt_floats(C, width);
     hipLaunchKernelGGL(k_cond_prep, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0,
                        (hipStream_t)stream, w1, w2, w3, logs, wt, C, width, logscale_factor);
+    IFL_HIP(hipGetLastError());
+    return IFL_OK;
+}
+
+int ifl_cond_prep_many_f32(const ifl_cond_prep_job *jobs, int n_jobs, size_t max_weights_floats, ifl_stream_t stream)
+{
+    clear_error();
+    if (n_jobs < 0) IFL_FAIL(IFL_EINVAL, "ifl_cond_prep_many_f32: n_jobs=%d", n_jobs);
+    if (n_jobs == 0) return IFL_OK;
+    if (!jobs || max_weights_floats == 0) IFL_FAIL(IFL_EINVAL, "ifl_cond_prep_many_f32: null job table or zero size");
+    if (n_jobs > 65535) IFL_FAIL(IFL_EUNSUPPORTED, "ifl_cond_prep_many_f32: at most 65535 jobs a call");
+    const size_t bl = (max_weights_floats + 255) / 256;
+    hipLaunchKernelGGL(k_cond_prep_many, dim3((unsigned)(bl < 64 ? bl : 64), (unsigned)n_jobs), dim3(256), 0, (hipStream_t)stream,
+                       (const PrepJob *)jobs);
     IFL_HIP(hipGetLastError());
     return IFL_OK;
 }

@@ -73,10 +73,11 @@ class _CondAffine(torch.autograd.Function):
 
     @staticmethod
     @_fwd32
-    def forward(ctx, x, w1, w2, w3, b3, logs, logscale, lowp):
+    def forward(ctx, x, w1, w2, w3, b3, logs, logscale, lowp, wt=None):
         x = x.contiguous()
         w1, w2 = w1.contiguous(), w2.contiguous()
-        wt = H.cond_prep(w1, w2, w3.contiguous(), logs.contiguous(), logscale)
+        if wt is None:  # (else: prepared for all couplings of the model in one launch, prepare_conditioners)
+            wt = H.cond_prep(w1, w2, w3.contiguous(), logs.contiguous(), logscale)
         a2, h = H.cond_forward(x, wt, w1, w2, b3, w3.shape[0], w1.shape[0])
         ctx.save_for_backward(x, h, a2, wt, w1)
         ctx.width = w1.shape[0]
@@ -89,7 +90,52 @@ class _CondAffine(torch.autograd.Function):
         x, h, a2, wt, w1 = ctx.saved_tensors
         gx, gh = H.coupling_backward(gy.contiguous(), gld.contiguous() if gld is not None else None, x, h)
         dw1, dw2, dw3, dlogs, db3 = H.cond_backward(x, gh, h, a2, wt, w1, gx, ctx.width, ctx.logscale, ctx.lowp)
-        return gx, dw1, dw2, dw3, (db3 if ctx.has_bias else None), dlogs, None, None
+        return gx, dw1, dw2, dw3, (db3 if ctx.has_bias else None), dlogs, None, None, None
+
+
+class ConditionerPrep:
+    """The weight images (transposed kernels + gain, csrc/conditioner.hip) of all fused couplings of a model in ONE launch.
+    A training step calls `fill()` before its forward pass and `release()` after its backward: between the two every
+    coupling takes its image from here instead of preparing it inside its own forward (a launch per layer: 30 a step for
+    the configs[3] model, 144 for configs[4]).  Outside that window -- and for couplings the fused path does not cover --
+    nothing changes.  The job table is rebuilt when a parameter has moved (e.g. re-homed into a flat optimizer buffer).
+    Only for models whose images together stay below `max_bytes` (8 MB: they then wait in the L2s for their layers): the
+    images of the configs[4] model (33 MB) prepared up front come back from memory, and its step got slower (30.0 ->
+    30.2 ms), where the configs[3] step gains 1 % (5.41 -> 5.35 ms)."""
+
+    def __init__(self, model, max_bytes=8 << 20):
+        self.layers = [m for m in model.modules() if isinstance(m, Coupling)]
+        self.table, self._active, self.max_bytes = None, [], max_bytes
+
+    def _entries(self):
+        act = []
+        for m in self.layers:
+            c1, c2, c3 = m.net[0], m.net[2], m.net[4]
+            ok = (m.fused and not m.uses_context and m.n_channels % 2 == 0 and c1.weight.is_cuda and c1.weight.dtype == torch.float32
+                  and H.cond_supported(m.n_channels, m.width) and isinstance(c3, Conv2dZero) and c3.kernel_size == (3, 3)
+                  and all(t.is_contiguous() for t in (c1.weight, c2.weight, c3.weight, c3.logs)))
+            if ok:
+                act.append((m, (c1.weight.detach(), c2.weight.detach(), c3.weight.detach(), c3.logs.detach(), c3.logscale_factor)))
+        return act
+
+    def fill(self):
+        act = self._entries()
+        ent = [e for _, e in act]
+        if self.table is None or self.table.stale(ent):
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                return  # (no table yet and a capture running: the couplings prepare their images themselves)
+            self.table = H.CondPrepTable(ent) if ent else None
+        if self.table is None or 4 * sum(w.numel() for w in self.table.wt) > self.max_bytes:
+            return
+        self.table.run()
+        self._active = [m for m, _ in act]
+        for m, wt in zip(self._active, self.table.wt):
+            m._prepared_wt = wt
+
+    def release(self):
+        for m in self._active:
+            m._prepared_wt = None
+        self._active = []
 
 
 def _on_library(x):
@@ -98,6 +144,7 @@ def _on_library(x):
 
 class Coupling(FlowLayer):
     channels_last = True  # the conditioner's 16-bit convolutions on NHWC operands (_net_channels_last)
+    _prepared_wt = None  # the weight image of THIS step, when a ConditionerPrep filled it (else the forward prepares it)
     fused = True  # conditioner + affine map on csrc/conditioner.hip where its shapes are covered (_CondAffine)
 
     def __init__(self, input_size, width=512, n_context=None):
@@ -158,7 +205,7 @@ class Coupling(FlowLayer):
             c1, c2, c3 = self.net[0], self.net[2], self.net[4]
             # (under bf16 autocast the weight gradients' GEMMs take bf16 operands -- the step's precision; fp32 otherwise)
             return _CondAffine.apply(input, c1.weight, c2.weight, c3.weight, c3.bias, c3.logs, c3.logscale_factor,
-                                     torch.is_autocast_enabled("cuda"))
+                                     torch.is_autocast_enabled("cuda"), self._prepared_wt)
         if _on_library(input):
             return _Affine.apply(input, self._conditioner(input, context))
         x1, x2, log_s, t = self.get_xs_logs_t(input, context)

@@ -13,11 +13,13 @@ nn.DataParallel (inf/if_multiGPU_imagenet32.py:410-411).  With autocast=True the
 boundary (inf/layers/*.py custom_fwd), the loss and the optimizer state stay fp32.
 """
 import math
+import time
 
 import torch
 
 import data_parallel as dp
 from inf.layers.inv_conv import inv_flow_with_pad
+from inf.layers.coupling import ConditionerPrep
 
 
 def get_loss(model, x):
@@ -48,8 +50,10 @@ class TrainStep:
 
     def __init__(self, model, optimizer, add_recon_grad=False, grad_clip_norm=None, grad_clip=None, clear_grads=False,
                  autocast=False, bucket=True, graph=False, graph_warmup=3, force_collective=False, conv_search=False,
-                 fused_optimizer=True, gather_grads=None, flat_optimizer=None):
+                 fused_optimizer=True, gather_grads=None, flat_optimizer=None, batch_cond_prep=True):
         self.model, self.optimizer = model, optimizer
+        # the weight images of all fused couplings in one launch at the head of the step (inf/layers/coupling.py)
+        self.cond_prep = ConditionerPrep(model) if batch_cond_prep else None
         self.add_recon_grad, self.grad_clip_norm, self.grad_clip = add_recon_grad, grad_clip_norm, grad_clip
         self.clear_grads, self.autocast = clear_grads, autocast
         self.force_collective = force_collective  # issue the bucket's all-reduce in a one-rank process group too (tests)
@@ -228,6 +232,12 @@ class TrainStep:
                 return loss
             self._static_x = x.clone()
             torch.cuda.synchronize()
+            if self._collective_due():
+                # ProcessGroupNCCL's watchdog retires a finished collective on its next poll (every 100 ms) by querying the
+                # work's event -- and HIP refuses the query of an event whose STREAM is capturing by then
+                # (hipErrorCapturedEvent ends the process; the warm-up's all-reduces were issued on the stream captured
+                # below).  Seen once in a few dozen runs.  All work is finished here: leave the watchdog a few polls.
+                time.sleep(0.5)
             # With a collective in the step the capture is cut in two AROUND it: [loss, backward] and [clip, optimizer], the
             # all-reduce of the bucket issued eagerly between the two replays.  (A captured RCCL all-reduce replays fine, but
             # ProcessGroupNCCL's watchdog queries the work's event, which was recorded in a capturing stream:
@@ -267,9 +277,15 @@ class TrainStep:
             self.bucket.zero()
         else:
             self.optimizer.zero_grad()
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.autocast and x.is_cuda):
-            lossval = get_loss(self.model, x)
-        lossval.backward()
+        if x.is_cuda and self.cond_prep is not None:
+            self.cond_prep.fill()  # (the couplings' weight images: one launch for all of them)
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.autocast and x.is_cuda):
+                lossval = get_loss(self.model, x)
+            lossval.backward()
+        finally:
+            if self.cond_prep is not None:
+                self.cond_prep.release()  # (the optimizer changes the kernels: the images are this step's only)
         if gather:
             self.bucket.gather()
         if self.add_recon_grad:  # experiment.py:284-285 (the SelfNormConv layers' reconstruction term)

@@ -8,6 +8,7 @@ tensor is not on the GPU the call raises.
 import ctypes
 import os
 
+import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -64,6 +65,7 @@ SIGNATURES = {
     "ifl_cond_weights_floats": (_sz, [_i, _i]),
     "ifl_cond_pixels_padded": (_i, [_i, _i, _i]),
     "ifl_cond_prep_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "ifl_cond_prep_many_f32": (_i, [_vp, _i, _sz, _vp]),
     "ifl_cond_forward_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ifl_cond_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "ifl_cond_grads_floats": (_sz, [_i, _i]),
@@ -640,6 +642,52 @@ def cond_prep(w1, w2, w3, logs, logscale_factor):
         rc = lib().ifl_cond_prep_f32(_ptr(w1), _ptr(w2), _ptr(w3), _ptr(logs), _ptr(wt), C, width, float(logscale_factor), _stream())
     _check(rc, "ifl_cond_prep_f32")
     return wt
+
+
+class CondPrepTable:
+    """The job table of ifl_cond_prep_many_f32 for a list of couplings' (w1, w2, w3, logs, logscale_factor): the weight
+    images `wt[i]` (persistent tensors, one per entry) and the device array of ifl_cond_prep_job.  `run()` refills every
+    image in one launch; `stale()` says whether a parameter has moved since the table was built."""
+    _JOB = np.dtype([("w1", "<u8"), ("w2", "<u8"), ("w3", "<u8"), ("logs", "<u8"), ("wt", "<u8"), ("C", "<i4"), ("width", "<i4"),
+                     ("logscale", "<f4"), ("reserved", "<i4")])
+
+    def __init__(self, entries):
+        assert self._JOB.itemsize == 56
+        self.n = len(entries)
+        self.wt, self._ptrs, self._keep = [], [], []
+        jobs = np.zeros(self.n, dtype=self._JOB)
+        self.max_floats, dev = 0, None
+        for i, (w1, w2, w3, logs, logscale) in enumerate(entries):
+            for t, n in ((w1, "w1"), (w2, "w2"), (w3, "w3"), (logs, "logs")):
+                _chk_tensor(t, n)
+            width, C = w1.shape[0], w3.shape[0]
+            if tuple(w1.shape) != (width, C // 2, 3, 3) or w2.numel() != C * width or tuple(w3.shape) != (C, C, 3, 3) or \
+                    logs.numel() != C or not cond_supported(C, width):
+                raise RuntimeError("CondPrepTable: entry %d is no supported conditioner (C=%d, width=%d)" % (i, C, width))
+            d = _same_device(w1, w2, w3, logs)
+            if dev is not None and d != dev:
+                raise RuntimeError("CondPrepTable: the couplings live on different devices")
+            dev = d
+            nfl = int(lib().ifl_cond_weights_floats(C, width))
+            wt = torch.empty(nfl, dtype=torch.float32, device=dev)
+            self.wt.append(wt)
+            self._keep.append((w1, w2, w3, logs))
+            self._ptrs.append((w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), logs.data_ptr()))
+            jobs[i] = (w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), logs.data_ptr(), wt.data_ptr(), C, width, float(logscale), 0)
+            self.max_floats = max(self.max_floats, nfl)
+        self.device = dev
+        self.jobs = torch.from_numpy(jobs.view(np.uint8).copy()).to(dev) if self.n else None
+
+    def stale(self, entries):
+        return len(entries) != self.n or any(
+            (e[0].data_ptr(), e[1].data_ptr(), e[2].data_ptr(), e[3].data_ptr()) != p for e, p in zip(entries, self._ptrs))
+
+    def run(self):
+        if not self.n:
+            return
+        with _on(self.device):
+            rc = lib().ifl_cond_prep_many_f32(_ptr(self.jobs), self.n, self.max_floats, _stream())
+        _check(rc, "ifl_cond_prep_many_f32")
 
 
 def cond_forward(x, wt, w1, w2, b3, C, width):

@@ -236,8 +236,9 @@ def test_conditioner_kernels_do_not_spill(tmp_path):
                    stderr=subprocess.PIPE)
     bodies, meta = kernels(open(out).read())
     cond = {k: v for k, v in meta.items() if "k_cond_" in k}
-    # prep, wreduce, wgrad x 2 operand types, and per channel count (7): fwd1m, fwd2, bwd3g, and x 2 operand types bwd1, bwd2m, bwd3u
-    assert len(cond) == 2 + 2 + 7 * (3 + 2 * 3), sorted(cond)
+    # prep, prep_many, wreduce, wgrad x 2 operand types, and per channel count (7): fwd1m, fwd2, bwd3g, and x 2 operand types
+    # bwd1, bwd2m, bwd3u
+    assert len(cond) == 3 + 2 + 7 * (3 + 2 * 3), sorted(cond)
     for name, m in cond.items():
         assert m["spill"] == 0 and m["scratch"] == 0 and m["vgpr"] <= 256, (name, m)
         assert not any(re.match(r"\s*(scratch_|buffer_(load|store))", ln) for ln in bodies[name]), name

@@ -102,3 +102,31 @@ def test_unsupported_shapes_keep_the_convolutions_and_bad_calls_fail_loudly():
     with pytest.raises(RuntimeError, match="not one of"):
         z = torch.zeros(8, device="cuda")
         Hh.cond_forward(x, z, z, z, None, 6, 64)
+
+
+@pytest.mark.gpu
+def test_weight_images_of_many_couplings_in_one_launch():
+    """ifl_cond_prep_many_f32 (the job table of invflow_hip.CondPrepTable) fills the weight images of couplings of different
+    shapes in one launch: every image identical, bit for bit, to ifl_cond_prep_f32's; a refill after the kernels changed
+    follows them; a parameter that moved makes the table stale; an unsupported shape is refused when the table is built."""
+    import invflow_hip as H
+    torch.manual_seed(3)
+    ents = []
+    for C, width in [(12, 128), (24, 128), (4, 512), (48, 256), (8, 64)]:
+        ents.append((torch.randn(width, C // 2, 3, 3, device="cuda"), torch.randn(C, width, 1, 1, device="cuda"),
+                     torch.randn(C, C, 3, 3, device="cuda"), torch.randn(C, 1, 1, device="cuda") * 0.1, 3.0))
+    table = H.CondPrepTable(ents)
+    for round_ in range(2):
+        table.run()
+        for (w1, w2, w3, logs, f), wt in zip(ents, table.wt):
+            assert torch.equal(wt, H.cond_prep(w1, w2, w3, logs, f))
+        for e in ents:
+            e[0].mul_(1.5); e[3].add_(0.01)  # (in place: the addresses stay)
+    assert not table.stale(ents)
+    moved = list(ents)
+    moved[2] = (ents[2][0].clone(),) + ents[2][1:]
+    assert table.stale(moved) and table.stale(ents[:-1])
+    with pytest.raises(RuntimeError):
+        H.CondPrepTable([(torch.randn(128, 5, 3, 3, device="cuda"), torch.randn(10, 128, 1, 1, device="cuda"),
+                          torch.randn(10, 10, 3, 3, device="cuda"), torch.zeros(10, 1, 1, device="cuda"), 3.0)])
+    assert H.CondPrepTable([]).n == 0

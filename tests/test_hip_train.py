@@ -218,6 +218,37 @@ def test_train_step_as_one_graph(fixture):
     assert seqs[1][-1] < seqs[1][0]
 
 
+def test_couplings_weight_images_prepared_in_one_launch_change_nothing():
+    """TrainStep(batch_cond_prep=True, the default) prepares the weight images of all fused couplings in one launch at the head
+    of the step (inf.layers.coupling.ConditionerPrep) instead of one launch inside every coupling's forward: the same
+    arithmetic on the same numbers -- the loss sequences with and without it are identical, eagerly and as a captured graph
+    (whose job table survives the re-homing of the parameters into the flat optimizer buffer); outside a step the layers
+    hold no prepared image."""
+    from inf.train.step import TrainStep
+    from inf.layers.coupling import Coupling
+    import inf.experiments.if_glow_cifar as mod
+    cfg = mod.DEFAULT_CONFIG
+    x = torch.randint(0, 256, (4, 3, 32, 32), device="cuda").float()
+    seqs = {}
+    for graph in (False, True):
+        for batched in (False, True):
+            torch.manual_seed(2)
+            model = mod.create_model(inv_flow=cfg["inv_flow"], inv_conv=cfg["inv_conv"], inv_conv_no_pad=cfg["inv_conv_no_pad"],
+                                     if_kernel_size=cfg["if_kernel_size"], num_blocks=2, block_size=2, coupling_width=32,
+                                     activation=cfg["activation"], actnorm=cfg["actnorm"], split_prior=cfg["split_prior"]).cuda()
+            step = TrainStep(model, torch.optim.Adam(model.parameters(), lr=1e-3), grad_clip_norm=1.0, autocast=True, graph=graph,
+                             graph_warmup=2, batch_cond_prep=batched)
+            seqs[graph, batched] = [float(step(x)) for _ in range(6)]
+            couplings = [m for m in model.modules() if isinstance(m, Coupling)]
+            assert couplings and all(m._prepared_wt is None for m in couplings)
+            if batched:
+                assert step.cond_prep.table is not None and step.cond_prep.table.n == len(couplings)
+                if graph:
+                    assert step._captured is not None
+    assert seqs[False, True] == seqs[False, False] and seqs[True, True] == seqs[True, False]
+    assert seqs[True, True][-1] < seqs[True, True][0]
+
+
 def test_clear_grads_keeps_the_bucket_and_changes_nothing(fixture):
     """TrainStep(clear_grads=True) masks the inverse-flow layers' gradients in place (they are views of the flat bucket): a run
     with it and a run without it take the same steps -- the library's dW is masked already -- eagerly and as a captured

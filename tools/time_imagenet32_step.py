@@ -14,7 +14,8 @@ for graph in ((True,) if "--graph-only" in sys.argv else (False, True)):
                          if_kernel_size=cfg["if_kernel_size"], num_blocks=cfg["num_blocks"], block_size=cfg["block_size"],
                          coupling_width=cfg["coupling_width"], activation=cfg["activation"], actnorm="--actnorm" in sys.argv or cfg["actnorm"],
                          split_prior=cfg["split_prior"]).to(dev)
-    step = TrainStep(model, torch.optim.Adam(model.parameters(), lr=cfg["lr"]), grad_clip_norm=1.0, autocast=True, graph=graph)
+    step = TrainStep(model, torch.optim.Adam(model.parameters(), lr=cfg["lr"]), grad_clip_norm=1.0, autocast=True, graph=graph,
+                     batch_cond_prep=os.environ.get("BATCH_PREP", "1") == "1")
     x = torch.randint(0, 256, (13, 3, 32, 32), device=dev).float()
     for _ in range(5):
         loss = step(x)

@@ -24,7 +24,8 @@ for which in (sys.argv[2:] or ["mnist", "cifar"]):
         model = mod.create_model(num_blocks=cfg["num_blocks"], block_size=cfg["block_size"], coupling_width=cfg["coupling_width"],
                                  n_bins=cfg["n_bins"], tail_bound=cfg["tail_bound"]).cuda()
         x = torch.randint(0, 256, (cfg["batch_size"], 1, 28, 28), device="cuda").float()
-    step = TrainStep(model, torch.optim.Adam(model.parameters(), lr=cfg["lr"]), grad_clip_norm=1.0, autocast=True, graph=True, conv_search=bm, fused_optimizer=fused)
+    step = TrainStep(model, torch.optim.Adam(model.parameters(), lr=cfg["lr"]), grad_clip_norm=1.0, autocast=True, graph=True, conv_search=bm, fused_optimizer=fused,
+                     batch_cond_prep=os.environ.get("BATCH_PREP", "1") == "1")
     for _ in range(6):
         loss = step(x)
     torch.cuda.synchronize(); t0 = time.perf_counter()

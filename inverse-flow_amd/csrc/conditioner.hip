@@ -369,7 +369,7 @@ __global__ __launch_bounds__(512) void k_cond_bwd1(const float *__restrict__ dh,
 // loads in flight), the patch [k][64] staged once.  The second product takes the wave's own 16 x 64 tile of relu(a1) -- out
 // through a wave-private LDS tile, back as the right-hand fragment -- against W2's 16 columns.
 template <int C> struct HCfg {
-    static constexpr int CIN = C / 2, K1 = 9 * CIN, K1P = (K1 + 3) / 4 * 4, KC = K1P > 64 ? 64 : 32, NKC = (K1P + KC - 1) / KC; // (64-wide chunks of W1 from C = 16: half the barrier-separated stages; configs[4] step 31.7 -> 31.4 ms)
+    static constexpr int CIN = C / 2, K1 = 9 * CIN, K1P = (K1 + 3) / 4 * 4, KC = K1P > 64 ? 64 : 32, NKC = (K1P + KC - 1) / KC; // (64-wide chunks of W1 from C = 16: half the barrier-separated stages; configs[4] step 31.7 -> 31.4 ms.  From C = 8 on: configs[2] 5.86 -> 6.03 ms)
     static constexpr int PST = 64 + 16, AST = KC + 1, HCH = 128;            // LDS row strides; hidden units per chunk
     static constexpr int P_FL = NKC * KC * PST, A_FL = HCH * AST, T_FL = 8 * 16 * PST; // patch (k padded to whole chunks), W1 chunk, tiles
     static constexpr int CP = (C + 15) / 16 * 16, MT2 = CP / 16;
